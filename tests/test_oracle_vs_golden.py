@@ -1,0 +1,194 @@
+"""Pin the CPU oracle (oracle/laed_oracle.py) to golden vectors produced by running the
+reference itself (tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_config, golden_params, load_golden, rel_err
+from oracle import laed_oracle as O
+
+TOL = 2e-6   # same torch build, same arithmetic, different op grouping -> fp32 round-off only
+
+
+@pytest.mark.parametrize("name", ["divae_tiny", "divae_mid"])
+def test_divae_forward_backward(name):
+    G = load_golden(name)
+    cfg = golden_config(G)
+    P = golden_params(G, requires_grad=True)
+    res = O.divae_forward(P, cfg, G["in/outputs"], G["in/u_steps"][0], training=True)
+    for k in ("nll", "reg_kl", "mi", "bpr"):
+        assert abs(float(res[k]) - float(G["out/" + k])) <= 1e-6 + 1e-5 * abs(float(G["out/" + k])), k
+    assert rel_err(res["log_qy"].detach(), G["out/log_qy"]) < TOL
+    assert np.array_equal(res["y_ids"].numpy(), G["out/y_ids"])
+    assert rel_err(res["dec_init_state"].detach(), G["out/dec_init_state"]) < TOL
+    assert rel_err(res["x_last"].detach(), G["out/x_last"][0]) < TOL
+    assert rel_err(res["tok_nll"].detach(), G["out/tok_nll"]) < 5e-6
+    assert abs(float(res["total"]) - float(G["out/total_loss"])) < 1e-5
+    res["total"].backward()
+    for k in O.trainable_keys(P):
+        assert rel_err(P[k].grad, G["grad/" + k]) < 2e-5, k
+    assert G["grad/log_py"].size == 0 and P["log_py"].grad is None
+
+
+@pytest.mark.parametrize("name", ["divst_tiny", "divst_mid"])
+def test_divst_forward_backward(name):
+    G = load_golden(name)
+    cfg = golden_config(G)
+    P = golden_params(G, requires_grad=True)
+    res = O.divst_forward(P, cfg, G["in/outputs"], G["in/prevs"], G["in/nexts"], G["in/u_steps"][0])
+    for k in ("prev_nll", "next_nll", "reg_kl", "mi", "b_pr"):
+        assert abs(float(res[k]) - float(G["out/" + k])) <= 1e-6 + 1e-5 * abs(float(G["out/" + k])), k
+    assert rel_err(res["prev_tok_nll"].detach(), G["out/prev_tok_nll"]) < 5e-6
+    assert rel_err(res["next_tok_nll"].detach(), G["out/next_tok_nll"]) < 5e-6
+    res["total"].backward()
+    for k in O.trainable_keys(P):
+        assert rel_err(P[k].grad, G["grad/" + k]) < 2e-5, k
+
+
+def _train5(G, kind):
+    cfg = golden_config(G)
+    P = golden_params(G, requires_grad=True)
+    keys = O.trainable_keys(P)
+    m = {k: torch.zeros_like(P[k]) for k in keys}
+    v = {k: torch.zeros_like(P[k]) for k in keys}
+    losses = []
+    out = {}
+    for s in range(5):
+        for k in keys:
+            P[k].grad = None
+        if kind == "divae":
+            res = O.divae_forward(P, cfg, G["in/outputs"], G["in/u_steps"][s])
+            losses.append([float(res[k]) for k in ("nll", "reg_kl", "mi", "bpr")])
+        else:
+            res = O.divst_forward(P, cfg, G["in/outputs"], G["in/prevs"], G["in/nexts"], G["in/u_steps"][s])
+            losses.append([float(res[k]) for k in ("prev_nll", "next_nll", "reg_kl", "mi", "b_pr")])
+        res["total"].backward()
+        with torch.no_grad():
+            for k in keys:
+                O.adam_step(P[k], P[k].grad, m[k], v[k], s + 1, lr=float(cfg.init_lr))
+        if s in (0, 4):
+            out[s + 1] = {k: P[k].detach().clone() for k in keys}
+    return cfg, P, np.array(losses), out
+
+
+@pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst"), ("divae_mid", "divae")])
+def test_adam_5_steps_and_greedy(name, kind):
+    G = load_golden(name)
+    cfg, P, losses, snaps = _train5(G, kind)
+    # Adam's first steps are sign-like (|dp| ~ lr), so tiny grads amplify round-off: abs tol in units of lr
+    for s in (1, 5):
+        for k, t in snaps[s].items():
+            d = np.max(np.abs(t.numpy() - G["p%d/%s" % (s, k)]))
+            assert d < 2e-5, (s, k, d)
+    assert np.allclose(losses, G["out/step_losses"], rtol=2e-4, atol=2e-6)
+    # greedy decode on the 5-step weights written by the reference (exact ids)
+    P5 = golden_params(G, prefix="p5/")
+    for k in list(P):
+        if k not in P5:
+            P5[k] = P["embedding.weight"].detach() if k.endswith("embedding.weight") else P[k].detach()
+    for k in list(P5):
+        if k.endswith("decoder.embedding.weight"):
+            P5[k] = P5["embedding.weight"]
+    with torch.no_grad():
+        if kind == "divae":
+            seq, lens, logp = O.divae_greedy(P5, cfg, G["in/outputs"], G["in/u_gen"])
+            assert np.array_equal(seq.numpy(), G["gen/sequence"])
+            assert lens == G["gen/length"].tolist()
+            ev = O.divae_forward(P5, cfg, G["in/outputs"], G["in/u_gen"], training=False)
+            for k in ("nll", "reg_kl", "mi", "bpr"):
+                assert abs(float(ev[k]) - float(G["eval/" + k])) <= 1e-6 + 2e-5 * abs(float(G["eval/" + k]))
+            assert np.array_equal(ev["y_ids"].numpy(), G["eval/y_ids"])
+        else:
+            (ps, pl, _), (ns, nl, _) = O.divst_greedy(P5, cfg, G["in/outputs"], G["in/u_gen"])
+            assert np.array_equal(ps.numpy(), G["gen/prev_sequence"])
+            assert np.array_equal(ns.numpy(), G["gen/next_sequence"])
+            assert pl == G["gen/prev_length"].tolist() and nl == G["gen/next_length"].tolist()
+
+
+def test_dropout_mask_case():
+    for name, kind in (("divae_tiny", "divae"), ("divst_tiny", "divst")):
+        G = load_golden(name)
+        cfg = golden_config(G)
+        cfg.dropout = 0.3
+        P = golden_params(G, requires_grad=True)
+        if kind == "divae":
+            res = O.divae_forward(P, cfg, G["in/outputs"], G["in/u_steps"][0], True, G["in/drop_mask0"])
+            keys = ("nll", "reg_kl", "mi", "bpr")
+        else:
+            res = O.divst_forward(P, cfg, G["in/outputs"], G["in/prevs"], G["in/nexts"], G["in/u_steps"][0],
+                                  True, (G["in/drop_mask0"], G["in/drop_mask1"]))
+            keys = ("prev_nll", "next_nll", "reg_kl", "mi", "b_pr")
+        for k in keys:
+            assert abs(float(res[k]) - float(G["drop/" + k])) <= 1e-6 + 1e-5 * abs(float(G["drop/" + k])), k
+        res["total"].backward()
+        for k in G.files:
+            if k.startswith("drop_grad/"):
+                assert rel_err(P[k[len("drop_grad/"):]].grad, G[k]) < 2e-5, k
+
+
+def test_modules():
+    G = load_golden("modules")
+    logits, u = torch.from_numpy(G["gumbel/logits"]), torch.from_numpy(G["gumbel/u"])
+    for temp in (1.0, 0.5):
+        lt = logits.clone().requires_grad_(True)
+        y, ids = O.gumbel_softmax(lt, u, temp, hard=False)
+        w = torch.from_numpy(np.arange(60, dtype=np.float32).reshape(12, 5) / 60.0)
+        (y * w).sum().backward()
+        assert rel_err(y.detach(), G["gumbel/y_t%g" % temp]) < TOL
+        assert np.array_equal(ids.numpy(), G["gumbel/ids_t%g" % temp])
+        assert rel_err(lt.grad, G["gumbel/dlogits_t%g" % temp]) < 1e-5
+    yh, ids = O.gumbel_softmax(logits, u, 1.0, hard=True)
+    assert np.array_equal(yh.numpy(), G["gumbel/y_hard"]) and np.array_equal(ids.numpy(), G["gumbel/ids_hard"])
+
+    logp, labels = torch.from_numpy(G["nll/logp"]), torch.from_numpy(G["nll/labels"])
+    for avg in (None, "seq", "real_word", "word"):
+        assert abs(float(O.nll_entropy(logp, labels, avg)) - float(G["nll/out_%s" % avg])) < 1e-5, avg
+
+    lq, lp = torch.from_numpy(G["catkl/log_qy"]), torch.from_numpy(G["catkl/log_py"])
+    assert abs(float(O.cat_kl(lq, lp, 4, True)) - float(G["catkl/unit"])) < 1e-6
+    assert abs(float(O.cat_kl(lq, lp, 4, False)) - float(G["catkl/batch"])) < 1e-6
+    assert abs(float(O.entropy(lq, None, True)) - float(G["entropy/unit"])) < 1e-6
+    assert abs(float(O.entropy(lq, 4, False)) - float(G["entropy/batch"])) < 1e-6
+
+    for bi in (0, 1):
+        tag = "enc_bi%d/" % bi
+        sd = {k[len(tag + "sd/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith(tag + "sd/")}
+        x, h0 = torch.from_numpy(G[tag + "x"]), torch.from_numpy(G[tag + "h0"])
+        for use_h0, sfx in ((False, ""), (True, "_h0")):
+            outs, hids = [], []
+            for d, rev in enumerate(["", "_reverse"][: bi + 1]):
+                hinit = h0[d] if use_h0 else torch.zeros_like(h0[d])
+                o, h = O.gru_seq(x, hinit, sd["rnn.weight_ih_l0" + rev], sd["rnn.weight_hh_l0" + rev],
+                                 sd["rnn.bias_ih_l0" + rev], sd["rnn.bias_hh_l0" + rev], reverse=bool(d))
+                outs.append(o)
+                hids.append(h)
+            assert rel_err(torch.cat(outs, dim=2), G[tag + "out" + sfx]) < TOL
+            assert rel_err(torch.stack(hids, dim=0), G[tag + "hid" + sfx]) < TOL
+
+    P = {k[len("dec/sd/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("dec/sd/")}
+    logp, hT = O.decoder_teacher(P, "", P["embedding.weight"], torch.from_numpy(G["dec/ids"]),
+                                 torch.from_numpy(G["dec/h0"])[0])
+    assert rel_err(logp, G["dec/logp"]) < TOL and rel_err(hT, G["dec/hid"][0]) < TOL
+    seq, lens, glp = O.decoder_greedy(P, "", P["embedding.weight"], torch.from_numpy(G["dec/h0"])[0], 6, 2, 3)
+    assert np.array_equal(seq.numpy(), G["dec/gen_seq"]) and lens == G["dec/gen_len"].tolist()
+    assert rel_err(glp, G["dec/gen_logp"]) < TOL
+
+    for has_bias in (0, 1):
+        tag = "linconn_b%d/" % has_bias
+        b = torch.from_numpy(G[tag + "b"]) if has_bias else None
+        out = torch.nn.functional.linear(torch.from_numpy(G[tag + "x"]), torch.from_numpy(G[tag + "w"]), b)
+        assert rel_err(out.unsqueeze(0), G[tag + "out"]) < TOL
+
+
+def test_module_form_matches_functional():
+    """The nn.Module oracle (what bench.py times as the CPU baseline) == functional oracle."""
+    G = load_golden("divae_tiny")
+    cfg = golden_config(G)
+    P = golden_params(G)
+    model = O.OracleDiVAE(int(G["config/vocab_size"]), cfg)
+    assert list(model.state_dict().keys()) == [str(k) for k in G["meta/state_dict_keys"]]
+    model.load_state_dict(P)
+    model.train()
+    res = model(G["in/outputs"], G["in/u_steps"][0])
+    for k in ("nll", "reg_kl", "mi", "bpr"):
+        assert abs(float(res[k]) - float(G["out/" + k])) <= 1e-6 + 1e-5 * abs(float(G["out/" + k])), k
