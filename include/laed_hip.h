@@ -1,0 +1,173 @@
+/*
+ * laed_hip.h -- C ABI of liblaed_hip.so: the MI355X (gfx950) kernels behind the DI-VAE / DI-VST
+ * train step of snakeztc/NeuralDialog-LAED.
+ *
+ * The reference has NO native boundary on this path: every op below is a stock torch.nn call made
+ * from Python.  Each entry point therefore cites the reference Python call site whose arithmetic it
+ * replaces (paths relative to the reference root).  A maintainer binds these with ctypes (see
+ * INTEGRATION.md); the in-tree binding is neuraldialog-laed_amd/laed_amd/_lib.py.
+ *
+ * Conventions
+ *   - all matrices are dense row-major fp32; token ids / labels are int64 (model_bases.py:53-57).
+ *   - sequence tensors are TIME-MAJOR inside the library: [T][B][*] (flat row = t*B + b).
+ *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch caching allocator);
+ *     the library allocates nothing and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - return value: 0 = ok, <0 = bad argument (LAED_E_*), >0 = hipError_t of a failed launch.
+ *     laed_last_error() returns a thread-local description of the last non-zero status.
+ *   - no global mutable state; reentrant across streams.
+ */
+#ifndef LAED_HIP_H
+#define LAED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAED_E_BADARG (-1)
+#define LAED_E_ALIGN  (-2)
+#define LAED_E_SIZE   (-3)
+
+int         laed_version(void);
+const char* laed_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32):  C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ C if accumulate)
+ *   transA = 0: A stored [M][K] (lda >= K);  transA = 1: A stored [K][M] (lda >= M)
+ *   transB = 0: B stored [K][N] (ldb >= N);  transB = 1: B stored [N][K] (ldb >= K)
+ *   colsum_a (optional, needs transA = 1): colsum_a[m] (+)= sum_k A[k][m]   (bias gradients)
+ * Replaces: nn.Linear forward  x W^T + b  (sent_models.py:53,110; nn_lib.py:145,158; decoders.py:149,165)
+ * and the two autograd GEMMs of its backward (dx = dy W, dW = dy^T x, db = colsum dy).
+ * ------------------------------------------------------------------------------------------ */
+int laed_sgemm(int transA, int transB, int M, int N, int K,
+               const float* A, int lda, const float* B, int ldb,
+               float* C, int ldc, const float* bias, int accumulate,
+               float* colsum_a, int colsum_accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding gather / scatter with optional input dropout.
+ *   out[r][:] = table[ids[r]][:] * (keep[r][:] ? 1/(1-p) : 0)            (keep == NULL: no dropout)
+ *   scatter: dtable[ids[r]][:] += dout[r][:] * (same factor), rows with ids[r] == pad_id skipped
+ * Replaces: nn.Embedding(padding_idx=PAD) (sent_models.py:44-45,99; decoders.py:155) and the
+ * decoder's nn.Dropout on the embedded inputs (base_modules.py:34; decoders.py:156).
+ * laed_dropout_keep_mask fills keep[n] (uint8 0/1) from a counter-based RNG keyed by
+ * (seed, offset + element index): results do not depend on how rows are split over GPUs.
+ * ------------------------------------------------------------------------------------------ */
+int laed_embed_gather(const int64_t* ids, int64_t rows, const float* table, int V, int E,
+                      const uint8_t* keep, float drop_p, float* out, void* stream);
+int laed_embed_scatter_add(const int64_t* ids, int64_t rows, const float* dout, int V, int E,
+                           const uint8_t* keep, float drop_p, int64_t pad_id, float* dtable, void* stream);
+int laed_dropout_keep_mask(uint8_t* keep, int64_t n, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+int laed_uniform(float* u, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GRU, 1 layer, uni-directional, gate order (r,z,n), time-major.
+ * Replaces nn.GRU(E,H,1,batch_first=True) built at base_modules.py:43-45 and called at
+ * encoders.py:62-64 / decoders.py:158, and its autograd backward.
+ *
+ *  fwd:  x[T][B][E]  ->  gates = x W_ih^T + b_ih (one MFMA GEMM for all T), then T launches of the fused
+ *        recurrent step kernel (h W_hh^T MFMA + gate epilogue).
+ *        hbuf [(T+1)][B][H]: hbuf[0] = h0 (copied in; h0 == NULL -> zeros), hbuf[t+1] = h_t.
+ *        gates[T][B][3H]   : overwritten with (r,z,n) (reserve for bwd; may be NULL with hn when save=0,
+ *                            then a [B][3H] scratch `gates` of one step is still required: pass T=1 per call)
+ *        hn   [T][B][H]    : W_hn h + b_hn (reserve for bwd)
+ *  bwd:  dout[T][B][H] (may be NULL), dhT[B][H] (may be NULL) ->
+ *        dx[T][B][E] (may be NULL), dw_ih[3H][E], dw_hh[3H][H], db_ih[3H], db_hh[3H], dh0[B][H]
+ *        gates is overwritten with d(gi); dgh[T][B][3H] is caller-provided workspace.
+ *        accumulate_w != 0: weight/bias grads are added to the existing contents.
+ * ------------------------------------------------------------------------------------------ */
+int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 const float* h0, int T, int B, int E, int H,
+                 float* hbuf, float* gates, float* hn, void* stream);
+int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh,
+                 const float* hbuf, float* gates, const float* hn,
+                 const float* dout, const float* dhT, int T, int B, int E, int H,
+                 float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                 float* dh0, int accumulate_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Posterior / Gumbel-softmax latent (rows R = B*y_size, k classes, k <= 64).
+ *   log_qy = log_softmax(logits)                         sent_models.py:110-111 ("Hidden2Discrete")
+ *   g = -log(-log(u+1e-20)+1e-20); y = softmax((logits+g)/tau); ids = argmax (first max);
+ *   hard: y = one_hot(ids)                               nn_lib.py:232-261 (GumbelConnector)
+ * bwd: dlogits = softmax-Jacobian(y, dy)/tau  (+)  log-softmax-Jacobian(log_qy, dlog_qy)
+ *   (dy == NULL or hard sample: first term skipped; dlog_qy == NULL: second term skipped)
+ * ------------------------------------------------------------------------------------------ */
+int laed_gumbel_latent_fwd(const float* logits, const float* u, int64_t R, int k, float tau, int hard,
+                           float* y, int64_t* ids, float* log_qy, void* stream);
+int laed_gumbel_latent_bwd(const float* y, const float* dy, const float* log_qy, const float* dlog_qy,
+                           int64_t R, int k, float tau, float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch-prior-regularised KL, MI (sent_models.py:138-156; criterions.py:97-109,136-147).
+ * Three phases so that a data-parallel job can all-reduce `stats` (y*k+2 floats) between 1 and 2:
+ *  1. laed_latent_stats:    stats[0..y*k) = sum_b q(y|x_b);  stats[y*k] = sum_rows H(q_row);
+ *                           stats[y*k+1] = sum_rows KL(q_row || uniform)          (local batch)
+ *                           workspace: nblk*(y*k+2) floats, nblk = laed_latent_stats_blocks()
+ *  2. laed_latent_finalize: scal[0]=bpr, scal[1]=mi, scal[2]=row-KL mean (use_mutual=False reg_kl),
+ *                           coef[y][k] = d bpr / d q[b][y][k]  (global batch size B_global)
+ *  3. laed_latent_bwd:      dlog_qy[r][:] (+)= gscale[0] * (use_mutual ? coef.*q : row-KL term)
+ * ------------------------------------------------------------------------------------------ */
+int laed_latent_stats_blocks(void);
+int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats, void* stream);
+int laed_latent_finalize(const float* stats, double B_global, int y, int k, float* scal, float* coef, void* stream);
+int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale, int use_mutual,
+                    int64_t B, double B_global, int y, int k, float* dlog_qy, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vocabulary projection fused with log-softmax + NLL (+ its backward), logits never materialised
+ * beyond a [chunk_rows][ldl] workspace.
+ * Replaces decoders.py:165-166 (project + log_softmax) and criterions.py:43-72 (F.nll_loss,
+ * ignore_index=PAD) plus their autograd backward.
+ *   h[N][H], W[V][H], b[V], labels[N] (int64; label == pad_id -> row ignored)
+ *   row_scale[N] (device, may be NULL = 1): per-row weight of the NLL in the final loss (e.g.
+ *       1/count_global for 'word' averaging) -- multiplies the gradients only.
+ *   outputs: tok_nll[N] = lse - logit[label] (0 on ignored rows), lse[N]
+ *   if with_grad: dh[N][H] = dL/dh, dW[V][H] (+)=, db[V] (+)= for  L = sum_r row_scale[r]*tok_nll[r]
+ *   workspace: chunk_rows*ldl floats, ldl = laed_proj_nll_ldl(V)
+ * ------------------------------------------------------------------------------------------ */
+int laed_proj_nll_ldl(int V);
+int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t* labels, const float* row_scale,
+                  int64_t N, int H, int V, int64_t pad_id, int with_grad, int accumulate_w,
+                  float* workspace, int chunk_rows,
+                  float* tok_nll, float* lse, float* dh, float* dW, float* db, void* stream);
+
+/* log-probabilities for callers that really want the [N][V] tensor (DecoderRNN's public contract,
+ * decoders.py:166): logp = logits - lse, in place on a caller buffer of [N][ldl]. */
+int laed_log_softmax_rows(float* logits, int64_t N, int V, int ldl, float* lse, void* stream);
+
+/* greedy symbol selection  ids[r] = argmax_v logits[r][v]  (lowest index on ties), decoders.py:218-219
+ * (topk(1) of log_softmax == argmax of logits). */
+int laed_argmax_rows(const float* logits, int64_t N, int V, int ldl, int64_t* ids, void* stream);
+
+/* Greedy free-running decode, max_len steps from h0 (DecoderRNN GEN/greedy, decoders.py:180-192,258-268):
+ * ids_out[(max_len+1)][B]: row 0 = go_id, row t+1 = symbols chosen at step t; hbuf[(max_len+1)][B][H] as in
+ * laed_gru_fwd; xbuf[B][E], gates[B][3H], logits[B][laed_proj_nll_ldl(V)] are caller-provided scratch. */
+int laed_gru_decode_greedy(const float* emb, const float* w_ih, const float* w_hh, const float* b_ih,
+                           const float* b_hh, const float* proj_w, const float* proj_b, const float* h0,
+                           int B, int E, int H, int V, int max_len, int64_t go_id,
+                           float* hbuf, float* xbuf, float* gates, float* logits, int64_t* ids_out, void* stream);
+
+/* masked reductions used by NLLEntropy's averaging modes (criterions.py:47-68):
+ * out[0] = sum_r tok_nll[r], out[1] = #(labels != pad). */
+int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int64_t N, int64_t pad_id, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam defaults; model_bases.py:122-125): in place on p, m, v.  `step` is 1-based.
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * ------------------------------------------------------------------------------------------ */
+int laed_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
+                   double lr, double beta1, double beta2, double eps, float grad_scale, void* stream);
+
+/* small utilities */
+int laed_dot(const float* a, const float* b, int64_t n, float* out, void* stream);      /* out[0] = sum a*b (one block, fixed order) */
+int laed_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream);   /* y = a*x + b*y */
+int laed_scale_by_dev(float* y, const float* x, const float* s, int64_t n, void* stream); /* y = s[0]*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAED_HIP_H */

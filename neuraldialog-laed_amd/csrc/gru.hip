@@ -1,0 +1,317 @@
+// GRU (1 layer, uni-directional, gates r,z,n), time-major, fp32.
+//
+// forward : gates = x W_ih^T + b_ih for all T at once (sgemm), then per timestep ONE fused kernel:
+//             gh = h_{t-1} W_hh^T (fp32 MFMA)  ->  gate epilogue in registers  ->  h_t, (r,z,n), hn
+//           The block tile is (32*WM batch rows) x (32 hidden units x 3 gates): a wave's three 32x32 MFMA
+//           accumulators are the r, z and n pre-activations of the SAME (row, unit) pairs, lane for lane, so the
+//           gate math needs no cross-lane traffic.  WK waves may split K (small batches) and are summed through LDS.
+// backward: per timestep (reverse): elementwise gate-gradient kernel, then dh_{t-1} += dgh_t W_hh (sgemm);
+//           after the loop three big GEMMs: dW_hh = dgh^T hprev, dW_ih = dgi^T x, dx = dgi W_ih
+//           (bias gradients fall out of the transposed-A GEMMs as column sums).
+// Time-major storage makes h_{t-1} for all (t,b) one plain matrix: hbuf[0 : T*B] (hbuf[0] = h0).
+#include "laed_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BK = 32;
+
+struct GruStepArgs {
+    const float* hprev;   // [B][H]
+    const float* w_hh;    // [3H][H]
+    const float* b_hh;    // [3H]
+    float* gates;         // [B][3H]  in: gi (+b_ih), out: r,z,n
+    float* hout;          // [B][H]
+    float* hn;            // [B][H] or NULL
+    int B, H;
+};
+
+// WM row tiles x WK K-splits, WM*WK == 4 waves
+template <int WM, int WK, bool VEC>
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
+    constexpr int BR = 32 * WM;        // batch rows per block
+    constexpr int SH = BR + 1;         // K-contiguous operands: transposing b32 writes, pad 1
+    constexpr int SW = 96 + 1;
+    constexpr int NLH = BR * BK / 4 / 256 > 0 ? BR * BK / 4 / 256 : 1;   // float4 per thread (h tile)
+    constexpr int NLW = 96 * BK / 4 / 256;                               // = 3
+    constexpr int TILE = BK * (SH + SW);
+    constexpr int RED = (WK > 1) ? (WK - 1) * WM * 64 * 48 : 0;
+    constexpr int SMEM = (2 * TILE > RED) ? 2 * TILE : RED;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* sH = smem;                  // [2][BK][SH]
+    float* sW = smem + 2 * BK * SH;    // [2][BK][SW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wq = wave / WM;
+    const int m0 = blockIdx.x * BR, j0 = blockIdx.y * 32;
+    const int B = p.B, H = p.H;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    float4 rh[NLH], rw[NLW];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            int idx = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < BR * BK / 4) {
+                int row = idx / (BK / 4), kq = idx % (BK / 4);
+                int gr = m0 + row, gk = k0 + 4 * kq;
+                if (gr < B && gk < H) {
+                    const float* src = p.hprev + (int64_t)gr * H + gk;
+                    if (VEC && gk + 3 < H) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (gk + 1 < H) v.y = src[1]; if (gk + 2 < H) v.z = src[2]; if (gk + 3 < H) v.w = src[3]; }
+                }
+            }
+            rh[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / (BK / 4), kq = idx % (BK / 4);   // row in [0,96): gate = row/32, unit = row%32
+            int unit = j0 + (row & 31), gk = k0 + 4 * kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (unit < H && gk < H) {
+                const float* src = p.w_hh + ((int64_t)(row >> 5) * H + unit) * H + gk;
+                if (VEC && gk + 3 < H) v = *reinterpret_cast<const float4*>(src);
+                else { v.x = src[0]; if (gk + 1 < H) v.y = src[1]; if (gk + 2 < H) v.z = src[2]; if (gk + 3 < H) v.w = src[3]; }
+            }
+            rw[i] = v;
+        }
+    };
+    auto store = [&](int buf) {
+        float* dh = sH + buf * BK * SH;
+        float* dw = sW + buf * BK * SW;
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            int idx = tid + i * 256;
+            if (idx < BR * BK / 4) {
+                int row = idx / (BK / 4), kq = idx % (BK / 4);
+                float* d = dh + (4 * kq) * SH + row;
+                d[0] = rh[i].x; d[SH] = rh[i].y; d[2 * SH] = rh[i].z; d[3 * SH] = rh[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / (BK / 4), kq = idx % (BK / 4);
+            float* d = dw + (4 * kq) * SW + row;
+            d[0] = rw[i].x; d[SW] = rw[i].y; d[2 * SW] = rw[i].z; d[3 * SW] = rw[i].w;
+        }
+    };
+
+    const int nkt = (H + BK - 1) / BK;
+    load(0);
+    store(0);
+    __syncthreads();
+    int cur = 0;
+    const int lrow = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) load((kt + 1) * BK);
+        const float* h_s = sH + cur * BK * SH + wm * 32 + lrow;
+        const float* w_s = sW + cur * BK * SW + lrow;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2 / WK; ++ks) {
+            const int krow = 2 * (wq + ks * WK) + lk;
+            float a = h_s[krow * SH];
+            float b0 = w_s[krow * SW], b1 = w_s[krow * SW + 32], b2 = w_s[krow * SW + 64];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+        }
+        if (more) store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (WK > 1) {   // sum the K-split partial accumulators into the wq == 0 waves
+        float* red = smem;   // all waves are past the last barrier: tiles are dead
+        if (wq > 0) {
+            float* d = red + (((wq - 1) * WM + wm) * 48) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d[(g * 16 + e) * 64] = acc[g][e];
+        }
+        __syncthreads();
+        if (wq == 0) {
+#pragma unroll
+            for (int s = 0; s < WK - 1; ++s) {
+                const float* d = red + ((s * WM + wm) * 48) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[g][e] += d[(g * 16 + e) * 64];
+            }
+        }
+    }
+    if (wq != 0) return;
+
+    const int j = j0 + lrow;
+    if (j >= H) return;
+    const float bhr = p.b_hh[j], bhz = p.b_hh[H + j], bhn = p.b_hh[2 * H + j];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row < B) {
+            float* g = p.gates + (int64_t)row * 3 * H;
+            const float ghn = acc[2][e] + bhn;
+            const float r = sigmoidf_acc(g[j] + acc[0][e] + bhr);
+            const float z = sigmoidf_acc(g[H + j] + acc[1][e] + bhz);
+            const float n = tanhf(g[2 * H + j] + r * ghn);
+            const float hp = p.hprev[(int64_t)row * H + j];
+            p.hout[(int64_t)row * H + j] = (1.0f - z) * n + z * hp;
+            if (p.hn != nullptr) {
+                g[j] = r; g[H + j] = z; g[2 * H + j] = n;
+                p.hn[(int64_t)row * H + j] = ghn;
+            }
+        }
+    }
+}
+
+template <int WM, int WK>
+int launch_step(const GruStepArgs& a, bool vec, hipStream_t stream) {
+    dim3 grid((a.B + 32 * WM - 1) / (32 * WM), (a.H + 31) / 32);
+    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false>), grid, dim3(256), 0, stream, a);
+    LAED_LAUNCH_CHECK("gru_step_fwd");
+    return 0;
+}
+
+int gru_step(const GruStepArgs& a, hipStream_t stream) {
+    const bool vec = aligned16(a.hprev) && aligned16(a.w_hh) && (a.H % 4 == 0);
+    const int64_t jt = (a.H + 31) / 32;
+    const char* env_wm = getenv("LAED_GRU_WM");   // test hook (4, 2 or 1): forces the block geometry
+    const int forced_wm = env_wm ? atoi(env_wm) : 0;
+    if (forced_wm == 4) return launch_step<4, 1>(a, vec, stream);
+    if (forced_wm == 2) return launch_step<2, 2>(a, vec, stream);
+    if (forced_wm == 1) return launch_step<1, 4>(a, vec, stream);
+    // widest row tile that still yields >= 256 blocks (one per CU); tiny batches split K over the waves instead
+    if (a.B > 64 && cdiv64(a.B, 128) * jt >= 256) return launch_step<4, 1>(a, vec, stream);
+    if (a.B > 32) return launch_step<2, 2>(a, vec, stream);
+    return launch_step<1, 4>(a, vec, stream);
+}
+
+// ---- backward, one timestep: gate gradients (elementwise over [B][H])
+struct GruBwdStepArgs {
+    const float* dout;    // [B][H] slice of dOut at t, or NULL
+    const float* hprev;   // [B][H]
+    const float* hn;      // [B][H]
+    float* gates;         // [B][3H] in: r,z,n ; out: d(gi)
+    float* dgh;           // [B][3H] out
+    float* dh;            // [B][H] in: carried dh_t (without dout) ; out: dh_t * z
+    int B, H;
+};
+
+__global__ __launch_bounds__(256) void gru_bwd_gates_kernel(GruBwdStepArgs p) {
+    const int64_t n = (int64_t)p.B * p.H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / p.H;
+        const int j = (int)(i - b * p.H);
+        float dh = p.dh[i];
+        if (p.dout != nullptr) dh += p.dout[i];
+        float* g = p.gates + b * 3 * p.H;
+        float* d = p.dgh + b * 3 * p.H;
+        const float r = g[j], z = g[p.H + j], nn = g[2 * p.H + j];
+        const float hn = p.hn[i], hp = p.hprev[i];
+        const float dn = dh * (1.0f - z);
+        const float dz = dh * (hp - nn);
+        const float dnp = dn * (1.0f - nn * nn);
+        const float dzp = dz * z * (1.0f - z);
+        const float drp = dnp * hn * r * (1.0f - r);
+        g[j] = drp; g[p.H + j] = dzp; g[2 * p.H + j] = dnp;
+        d[j] = drp; d[p.H + j] = dzp; d[2 * p.H + j] = dnp * r;
+        p.dh[i] = dh * z;
+    }
+}
+
+}   // namespace
+
+int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
+                       int B, int H, hipStream_t stream) {
+    GruStepArgs a;
+    a.hprev = hprev; a.w_hh = w_hh; a.b_hh = b_hh; a.gates = gates; a.hout = hout; a.hn = hn; a.B = B; a.H = H;
+    return gru_step(a, stream);
+}
+
+extern "C" int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                            const float* h0, int T, int B, int E, int H,
+                            float* hbuf, float* gates, float* hn, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAED_CHECK_ARG(T > 0 && B > 0 && E > 0 && H > 0, "gru_fwd: non-positive dimension");
+    LAED_CHECK_ARG(x && w_ih && w_hh && b_ih && b_hh && hbuf && gates, "gru_fwd: null pointer");
+    const int64_t BH = (int64_t)B * H;
+    LAED_CHECK_ARG((int64_t)T * B < 0x7fffffff, "gru_fwd: T*B too large");
+    if (h0 != nullptr) {
+        if (h0 != hbuf) {
+            hipError_t e = hipMemcpyAsync(hbuf, h0, BH * sizeof(float), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return laed_fail((int)e, "gru_fwd: h0 copy failed");
+        }
+    } else {
+        hipError_t e = hipMemsetAsync(hbuf, 0, BH * sizeof(float), stream);
+        if (e != hipSuccess) return laed_fail((int)e, "gru_fwd: h0 memset failed");
+    }
+    // hoisted input projection for every timestep: gates[T*B][3H] = x[T*B][E] W_ih^T + b_ih
+    LAED_TRY(laed_sgemm_impl(false, true, T * B, 3 * H, E, x, E, w_ih, E, gates, 3 * H, b_ih, false, nullptr, false, stream));
+    for (int t = 0; t < T; ++t) {
+        GruStepArgs a;
+        a.hprev = hbuf + (int64_t)t * BH;
+        a.w_hh = w_hh;
+        a.b_hh = b_hh;
+        a.gates = gates + (int64_t)t * B * 3 * H;
+        a.hout = hbuf + (int64_t)(t + 1) * BH;
+        a.hn = hn ? hn + (int64_t)t * BH : nullptr;
+        a.B = B;
+        a.H = H;
+        LAED_TRY(gru_step(a, stream));
+    }
+    return 0;
+}
+
+extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh,
+                            const float* hbuf, float* gates, const float* hn,
+                            const float* dout, const float* dhT, int T, int B, int E, int H,
+                            float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                            float* dh0, int accumulate_w, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAED_CHECK_ARG(T > 0 && B > 0 && E > 0 && H > 0, "gru_bwd: non-positive dimension");
+    LAED_CHECK_ARG(x && w_ih && w_hh && hbuf && gates && hn && dgh && dw_ih && dw_hh && db_ih && db_hh && dh0,
+                   "gru_bwd: null pointer");
+    LAED_CHECK_ARG((int64_t)T * B < 0x7fffffff, "gru_bwd: T*B too large");
+    const int64_t BH = (int64_t)B * H;
+    hipError_t e;
+    if (dhT != nullptr) e = hipMemcpyAsync(dh0, dhT, BH * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    else e = hipMemsetAsync(dh0, 0, BH * sizeof(float), stream);
+    if (e != hipSuccess) return laed_fail((int)e, "gru_bwd: dh init failed");
+    const int nblk = (int)((BH + 255) / 256 < 2048 ? (BH + 255) / 256 : 2048);
+    for (int t = T - 1; t >= 0; --t) {
+        GruBwdStepArgs a;
+        a.dout = dout ? dout + (int64_t)t * BH : nullptr;
+        a.hprev = hbuf + (int64_t)t * BH;
+        a.hn = hn + (int64_t)t * BH;
+        a.gates = gates + (int64_t)t * B * 3 * H;
+        a.dgh = dgh + (int64_t)t * B * 3 * H;
+        a.dh = dh0;
+        a.B = B;
+        a.H = H;
+        hipLaunchKernelGGL(gru_bwd_gates_kernel, dim3(nblk), dim3(256), 0, stream, a);
+        LAED_LAUNCH_CHECK("gru_bwd_gates");
+        // dh_{t-1} = dh_t * z + dgh_t W_hh      ([B][3H] x [3H][H])
+        LAED_TRY(laed_sgemm_impl(false, false, B, H, 3 * H, a.dgh, 3 * H, w_hh, H, dh0, H, nullptr, true, nullptr, false, stream));
+    }
+    const bool acc = accumulate_w != 0;
+    const int TB = T * B;
+    // dW_hh[3H][H] = dgh^T[3H][TB] hprev[TB][H] ; db_hh = colsum(dgh)
+    LAED_TRY(laed_sgemm_impl(true, false, 3 * H, H, TB, dgh, 3 * H, hbuf, H, dw_hh, H, nullptr, acc, db_hh, acc, stream));
+    // dW_ih[3H][E] = dgi^T[3H][TB] x[TB][E] ; db_ih = colsum(dgi)
+    LAED_TRY(laed_sgemm_impl(true, false, 3 * H, E, TB, gates, 3 * H, x, E, dw_ih, E, nullptr, acc, db_ih, acc, stream));
+    // dx[TB][E] = dgi[TB][3H] W_ih[3H][E]
+    if (dx != nullptr)
+        LAED_TRY(laed_sgemm_impl(false, false, TB, E, 3 * H, gates, 3 * H, w_ih, E, dx, E, nullptr, false, nullptr, false, stream));
+    return 0;
+}

@@ -1,0 +1,67 @@
+// Internal helpers shared by the kernels of liblaed_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/laed_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+char* laed_err_buf();   // thread-local, 256 bytes (laed_api.hip)
+
+static inline int laed_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(laed_err_buf(), 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LAED_CHECK_ARG(cond, ...) \
+    do { if (!(cond)) return laed_fail(LAED_E_BADARG, __VA_ARGS__); } while (0)
+
+#define LAED_LAUNCH_CHECK(name) \
+    do { hipError_t e_ = hipGetLastError(); \
+         if (e_ != hipSuccess) return laed_fail((int)e_, "%s launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+#define LAED_TRY(expr) do { int s_ = (expr); if (s_ != 0) return s_; } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// internal entry shared by gru / proj_nll / api
+int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, bool accumulate,
+                    float* colsum_a, bool colsum_accumulate, hipStream_t stream);
+
+int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
+                       int B, int H, hipStream_t stream);
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based RNG: splitmix64-style hash of (seed, index) -> uniform in [0,1)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+    uint64_t r = mix64(mix64(seed) ^ (idx * 0xD6E8FEB86659FD93ull));
+    return (float)(r >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+}

@@ -1,0 +1,262 @@
+// Discrete-latent kernels: posterior log-softmax + Gumbel-softmax sample (fwd/bwd) and the
+// batch-prior-regularised KL / mutual-information statistics.  All are tiny HBM-bound row reductions:
+// a row of k <= 64 classes lives on a W-lane sub-group of a wavefront (W = 16/32/64) and is reduced with
+// __shfl_xor, so one 64-lane wave handles 64/W rows per instruction.
+#include "laed_common.h"
+#include <math.h>
+
+namespace {
+
+template <int W>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float grp_max(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, W));
+    return v;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void gumbel_latent_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
+                                                                int64_t R, int k, float tau, int hard,
+                                                                float* __restrict__ y, int64_t* __restrict__ ids,
+                                                                float* __restrict__ log_qy) {
+    constexpr int RPB = 256 / W;
+    const int c = threadIdx.x % W;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / W;
+    const bool valid = (row < R) && (c < k);
+    const int64_t off = valid ? row * k + c : 0;
+    const float l = valid ? logits[off] : -INFINITY;
+
+    // log q(y|x) = log_softmax(logits)                         (sent_models.py:111)
+    const float m = grp_max<W>(l);
+    const float e = valid ? expf(l - m) : 0.f;
+    const float s = grp_sum<W>(e);
+    if (valid && log_qy != nullptr) log_qy[off] = (l - m) - logf(s);
+
+    // y = softmax((logits + g)/tau), g = -log(-log(u+eps)+eps)  (nn_lib.py:232-242)
+    float a = -INFINITY;
+    if (valid) {
+        const float g = -logf(-logf(u[off] + 1e-20f) + 1e-20f);
+        a = (l + g) / tau;
+    }
+    const float m2 = grp_max<W>(a);
+    const float e2 = valid ? expf(a - m2) : 0.f;
+    const float s2 = grp_sum<W>(e2);
+    float yv = e2 / s2;
+
+    // ids = argmax_k y, first maximum                            (nn_lib.py:253)
+    float bv = valid ? yv : -1.f;
+    int bi = c;
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, W);
+        const int oi = __shfl_xor(bi, o, W);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (hard) yv = (c == bi) ? 1.f : 0.f;                        // nn_lib.py:254-257
+    if (valid) {
+        y[off] = yv;
+        if (c == 0 && ids != nullptr) ids[row] = bi;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void gumbel_latent_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                const float* __restrict__ log_qy, const float* __restrict__ dlog_qy,
+                                                                int64_t R, int k, float tau, float* __restrict__ dlogits) {
+    constexpr int RPB = 256 / W;
+    const int c = threadIdx.x % W;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / W;
+    const bool valid = (row < R) && (c < k);
+    const int64_t off = valid ? row * k + c : 0;
+    float out = 0.f;
+    if (dy != nullptr) {   // y = softmax(a), a = (logits+g)/tau : dlogits = y*(dy - sum(dy*y))/tau
+        const float yv = valid ? y[off] : 0.f;
+        const float dv = valid ? dy[off] : 0.f;
+        const float dot = grp_sum<W>(yv * dv);
+        out += yv * (dv - dot) / tau;
+    }
+    if (dlog_qy != nullptr) {   // log_softmax: dlogits = dlq - q*sum(dlq)
+        const float dv = valid ? dlog_qy[off] : 0.f;
+        const float q = valid ? expf(log_qy[off]) : 0.f;
+        const float sm = grp_sum<W>(dv);
+        out += dv - q * sm;
+    }
+    if (valid) dlogits[off] = out;
+}
+
+// ---- BPR / MI statistics -------------------------------------------------------------------
+constexpr int STAT_BLOCKS = 128;
+constexpr int MAXE = 8;   // y*k <= 8*256
+
+__global__ __launch_bounds__(256) void latent_stats_kernel(const float* __restrict__ log_qy, int64_t B, int yk, int k,
+                                                           float* __restrict__ ws) {
+    __shared__ float red[2][4];
+    float sq[MAXE];
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) sq[i] = 0.f;
+    float ent = 0.f, kl = 0.f;
+    const float logu = logf(1.0f / (float)k);
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const float* row = log_qy + b * yk;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int e = threadIdx.x + i * 256;
+            if (e < yk) {
+                const float lq = row[e];
+                const float q = expf(lq);
+                sq[i] += q;
+                ent += -1.0f * lq * q;
+                kl += q * (lq - logu);
+            }
+        }
+    }
+    float* out = ws + (int64_t)blockIdx.x * (yk + 2);
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int e = threadIdx.x + i * 256;
+        if (e < yk) out[e] = sq[i];
+    }
+    ent = wave_sum(ent);
+    kl = wave_sum(kl);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = ent; red[1][wave] = kl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[yk] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        out[yk + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void latent_stats_combine_kernel(const float* __restrict__ ws, int nblk, int n,
+                                                                   float* __restrict__ stats) {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += ws[(int64_t)b * n + e];   // fixed order: reproducible
+        stats[e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void latent_finalize_kernel(const float* __restrict__ stats, float Bg, int y, int k,
+                                                              float* __restrict__ scal, float* __restrict__ coef) {
+    // one block; thread e handles class element e of [y][k]; per-y sums through LDS
+    __shared__ float s_kl[MAXE * 256], s_h[MAXE * 256];
+    const int yk = y * k;
+    const float logu = logf(1.0f / (float)k);
+    for (int e = threadIdx.x; e < yk; e += blockDim.x) {
+        const float qbar = stats[e] / Bg;                       // torch.mean(dim=0)
+        const float l = logf(qbar + 1e-15f);                    // sent_models.py:139
+        const float el = expf(l);                               // CatKLLoss recomputes exp(log) (criterions.py:104)
+        s_kl[e] = el * (l - logu);
+        s_h[e] = -1.0f * l * el;
+        if (coef != nullptr) coef[e] = el * ((l - logu) + 1.0f) / (qbar + 1e-15f) / ((float)y * Bg);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bpr = 0.f, hq = 0.f;
+        for (int yy = 0; yy < y; ++yy) {
+            float a = 0.f, h = 0.f;
+            for (int c = 0; c < k; ++c) { a += s_kl[yy * k + c]; h += s_h[yy * k + c]; }
+            bpr += a;
+            hq += h;
+        }
+        bpr /= (float)y;                                        // unit_average=True -> mean over the y rows
+        hq /= (float)y;
+        const float rows = (float)y * Bg;
+        scal[0] = bpr;
+        scal[1] = hq - stats[yk] / rows;                        // mi = H(avg) - mean_rows H(q)   (sent_models.py:155-156)
+        scal[2] = stats[yk + 1] / rows;                         // non-mutual reg_kl               (sent_models.py:150-151)
+        scal[3] = hq;
+    }
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ log_qy, const float* __restrict__ coef,
+                                                         const float* __restrict__ gscale, int use_mutual, int64_t n,
+                                                         int yk, int k, float rows_g, float* __restrict__ dlog_qy,
+                                                         int accumulate) {
+    const float g = gscale ? gscale[0] : 1.0f;
+    const float logu = logf(1.0f / (float)k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float lq = log_qy[i];
+        const float q = expf(lq);
+        float d;
+        if (use_mutual) d = g * coef[i % yk] * q;               // d bpr / d log_qy = coef * q
+        else d = g * q * ((lq - logu) + 1.0f) / rows_g;
+        dlog_qy[i] = accumulate ? dlog_qy[i] + d : d;
+    }
+}
+
+}   // namespace
+
+#define DISPATCH_W(k, CALL)                         \
+    do {                                            \
+        if ((k) <= 16) { CALL(16); }                \
+        else if ((k) <= 32) { CALL(32); }           \
+        else { CALL(64); }                          \
+    } while (0)
+
+extern "C" int laed_gumbel_latent_fwd(const float* logits, const float* u, int64_t R, int k, float tau, int hard,
+                                      float* y, int64_t* ids, float* log_qy, void* stream) {
+    LAED_CHECK_ARG(R >= 0 && k > 0 && k <= 64, "gumbel_latent_fwd: need 0 < k <= 64 (got %d)", k);
+    LAED_CHECK_ARG(tau > 0.f, "gumbel_latent_fwd: temperature must be positive");
+    if (R == 0) return 0;
+    LAED_CHECK_ARG(logits && u && y, "gumbel_latent_fwd: null pointer");
+#define CALL(W) hipLaunchKernelGGL((gumbel_latent_fwd_kernel<W>), dim3((unsigned)cdiv64(R, 256 / W)), dim3(256), 0, \
+                                   (hipStream_t)stream, logits, u, R, k, tau, hard, y, ids, log_qy)
+    DISPATCH_W(k, CALL);
+#undef CALL
+    LAED_LAUNCH_CHECK("gumbel_latent_fwd");
+    return 0;
+}
+
+extern "C" int laed_gumbel_latent_bwd(const float* y, const float* dy, const float* log_qy, const float* dlog_qy,
+                                      int64_t R, int k, float tau, float* dlogits, void* stream) {
+    LAED_CHECK_ARG(R >= 0 && k > 0 && k <= 64, "gumbel_latent_bwd: need 0 < k <= 64 (got %d)", k);
+    if (R == 0) return 0;
+    LAED_CHECK_ARG(dlogits && (dy == nullptr || y) && (dlog_qy == nullptr || log_qy), "gumbel_latent_bwd: null pointer");
+#define CALL(W) hipLaunchKernelGGL((gumbel_latent_bwd_kernel<W>), dim3((unsigned)cdiv64(R, 256 / W)), dim3(256), 0, \
+                                   (hipStream_t)stream, y, dy, log_qy, dlog_qy, R, k, tau, dlogits)
+    DISPATCH_W(k, CALL);
+#undef CALL
+    LAED_LAUNCH_CHECK("gumbel_latent_bwd");
+    return 0;
+}
+
+extern "C" int laed_latent_stats_blocks(void) { return STAT_BLOCKS; }
+
+extern "C" int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats, void* stream) {
+    LAED_CHECK_ARG(B > 0 && y > 0 && k > 0 && y * k <= MAXE * 256, "latent_stats: need y*k <= %d", MAXE * 256);
+    LAED_CHECK_ARG(log_qy && workspace && stats, "latent_stats: null pointer");
+    const int yk = y * k;
+    const int nblk = (int)(B < STAT_BLOCKS ? B : STAT_BLOCKS);
+    hipLaunchKernelGGL(latent_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, B, yk, k, workspace);
+    LAED_LAUNCH_CHECK("latent_stats");
+    hipLaunchKernelGGL(latent_stats_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nblk, yk + 2, stats);
+    LAED_LAUNCH_CHECK("latent_stats_combine");
+    return 0;
+}
+
+extern "C" int laed_latent_finalize(const float* stats, double B_global, int y, int k, float* scal, float* coef, void* stream) {
+    LAED_CHECK_ARG(B_global > 0 && y > 0 && k > 0 && y * k <= MAXE * 256, "latent_finalize: bad size");
+    LAED_CHECK_ARG(stats && scal, "latent_finalize: null pointer");
+    hipLaunchKernelGGL(latent_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, (float)B_global, y, k, scal, coef);
+    LAED_LAUNCH_CHECK("latent_finalize");
+    return 0;
+}
+
+extern "C" int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale, int use_mutual,
+                               int64_t B, double B_global, int y, int k, float* dlog_qy, int accumulate, void* stream) {
+    LAED_CHECK_ARG(B > 0 && y > 0 && k > 0, "latent_bwd: bad size");
+    LAED_CHECK_ARG(log_qy && dlog_qy && (!use_mutual || coef), "latent_bwd: null pointer");
+    const int64_t n = B * y * k;
+    const int nblk = (int)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, coef, gscale, use_mutual, n,
+                       y * k, k, (float)(B_global * y), dlog_qy, accumulate);
+    LAED_LAUNCH_CHECK("latent_bwd");
+    return 0;
+}

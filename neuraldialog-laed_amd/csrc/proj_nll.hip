@@ -1,0 +1,250 @@
+// Vocabulary projection fused with log-softmax + NLL and its backward.
+//
+// The [N][V] logits / log-prob tensor of the reference (decoders.py:165-166; 31.9 GB at the scaled shape)
+// is never materialised.  Rows are processed in chunks of `chunk_rows`; per chunk, on one stream:
+//   1. L = h_chunk W^T + b                         fp32 MFMA GEMM into the [chunk][ldl] workspace
+//   2. row kernel: lse, tok_nll = lse - L[label];  L <- (softmax(L) - onehot(label)) * row_scale   in place
+//   3. dh_chunk = L W                              fp32 MFMA GEMM
+//   4. dW += L^T h_chunk,  db += colsum(L)         fp32 MFMA GEMM (bias gradient from its A-operand loads)
+// i.e. exactly the 3 x 2NHV algorithmic FLOPs of forward+backward (no recomputation), and the workspace
+// round trips are ~1 ps/logit of HBM/MALL traffic against ~13 ps/logit of fp32 MFMA time.
+// A forward-only call (with_grad = 0: validation) stops after step 2 without the in-place rewrite.
+#include "laed_common.h"
+#include <math.h>
+
+namespace {
+
+enum { MODE_STATS = 0, MODE_GRAD = 1, MODE_LOGP = 2 };
+
+struct MS { float m, s; };
+__device__ __forceinline__ MS ms_combine(MS a, MS b) {
+    const float m = fmaxf(a.m, b.m);
+    MS r;
+    r.m = m;
+    r.s = (a.m == -INFINITY ? 0.f : a.s * expf(a.m - m)) + (b.m == -INFINITY ? 0.f : b.s * expf(b.m - m));
+    return r;
+}
+
+// one block per row (grid-stride); 256 threads; float4 accesses (ldl % 4 == 0, workspace 16-byte aligned)
+template <int MODE>
+__global__ __launch_bounds__(256) void proj_rows_kernel(float* __restrict__ L, int64_t rows, int V, int64_t ldl,
+                                                        const int64_t* __restrict__ labels, const float* __restrict__ row_scale,
+                                                        int64_t pad_id, float* __restrict__ tok_nll, float* __restrict__ lse_out) {
+    __shared__ float sm[4], ss[4];
+    __shared__ float s_lab;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V4 = V >> 2;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        float* Lr = L + row * ldl;
+        const float4* Lr4 = reinterpret_cast<const float4*>(Lr);
+        int64_t lab = (labels != nullptr) ? labels[row] : -1;
+        const bool ignored = (labels != nullptr) && (lab == pad_id || lab < 0 || lab >= V);
+        if (MODE == MODE_GRAD && ignored) {   // ignored rows: zero loss, zero gradient
+            for (int i = tid; i < V4; i += 256) reinterpret_cast<float4*>(Lr)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = V4 * 4 + tid; i < V; i += 256) Lr[i] = 0.f;
+            if (tid == 0) { tok_nll[row] = 0.f; if (lse_out) lse_out[row] = 0.f; }
+            continue;
+        }
+        // pass 1: online max / sum-exp
+        MS t;
+        t.m = -INFINITY;
+        t.s = 0.f;
+        for (int i = tid; i < V4; i += 256) {
+            const float4 x = Lr4[i];
+            const float cm = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+            const float m = fmaxf(t.m, cm);
+            t.s = t.s * expf(t.m - m) + (expf(x.x - m) + expf(x.y - m)) + (expf(x.z - m) + expf(x.w - m));
+            t.m = m;
+        }
+        for (int i = V4 * 4 + tid; i < V; i += 256) {
+            const float x = Lr[i];
+            const float m = fmaxf(t.m, x);
+            t.s = t.s * expf(t.m - m) + expf(x - m);
+            t.m = m;
+        }
+        if (t.m == -INFINITY) t.s = 0.f;   // thread saw no element (exp(-inf - -inf) = nan guard)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            MS ot;
+            ot.m = __shfl_xor(t.m, o, 64);
+            ot.s = __shfl_xor(t.s, o, 64);
+            t = ms_combine(t, ot);
+        }
+        if (lane == 0) { sm[wave] = t.m; ss[wave] = t.s; }
+        if (tid == 0 && labels != nullptr && !ignored) s_lab = Lr[lab];
+        __syncthreads();
+        MS a, b, c, d;
+        a.m = sm[0]; a.s = ss[0]; b.m = sm[1]; b.s = ss[1]; c.m = sm[2]; c.s = ss[2]; d.m = sm[3]; d.s = ss[3];
+        const MS tot = ms_combine(ms_combine(a, b), ms_combine(c, d));
+        const float lse = tot.m + logf(tot.s);
+        if (tid == 0) {
+            if (lse_out) lse_out[row] = lse;
+            if (tok_nll) tok_nll[row] = ignored ? 0.f : (labels != nullptr ? lse - s_lab : 0.f);
+        }
+        if (MODE == MODE_GRAD) {
+            const float g = row_scale ? row_scale[row] : 1.0f;
+            const int lab_i = (int)lab;
+            for (int i = tid; i < V4; i += 256) {
+                float4 x = Lr4[i];
+                x.x = expf(x.x - lse); x.y = expf(x.y - lse); x.z = expf(x.z - lse); x.w = expf(x.w - lse);
+                const int c0 = i * 4;
+                if (lab_i >= c0 && lab_i < c0 + 4) {
+                    if (lab_i == c0) x.x -= 1.0f; else if (lab_i == c0 + 1) x.y -= 1.0f;
+                    else if (lab_i == c0 + 2) x.z -= 1.0f; else x.w -= 1.0f;
+                }
+                x.x *= g; x.y *= g; x.z *= g; x.w *= g;
+                reinterpret_cast<float4*>(Lr)[i] = x;
+            }
+            for (int i = V4 * 4 + tid; i < V; i += 256) {
+                float x = expf(Lr[i] - lse);
+                if (i == lab_i) x -= 1.0f;
+                Lr[i] = x * g;
+            }
+        } else if (MODE == MODE_LOGP) {
+            for (int i = tid; i < V4; i += 256) {
+                float4 x = Lr4[i];
+                x.x -= lse; x.y -= lse; x.z -= lse; x.w -= lse;
+                reinterpret_cast<float4*>(Lr)[i] = x;
+            }
+            for (int i = V4 * 4 + tid; i < V; i += 256) Lr[i] -= lse;
+        }
+        __syncthreads();   // sm/ss/s_lab reused by the next row
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ L, int64_t rows, int V, int64_t ldl,
+                                                          int64_t* __restrict__ ids) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* Lr = L + row * ldl;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            const float x = Lr[i];
+            if (x > bv) { bv = x; bi = i; }   // ascending i per thread: first max kept
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+            ids[row] = bi;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void nll_reduce_kernel(const float* __restrict__ tok, const int64_t* __restrict__ labels,
+                                                          int64_t N, int64_t pad_id, float* __restrict__ out) {
+    __shared__ float ss[16], sc[16];
+    float s = 0.f, c = 0.f;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) {
+        if (labels[i] != pad_id) { s += tok[i]; c += 1.0f; }
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 16; ++w) { a += ss[w]; b += sc[w]; }
+        out[0] = a;
+        out[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(1024) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                   float* __restrict__ out) {
+    __shared__ float ss[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += ss[w];
+        out[0] = t;
+    }
+}
+
+inline int rows_grid(int64_t rows) { return (int)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
+
+}   // namespace
+
+extern "C" int laed_proj_nll_ldl(int V) { return (V + 31) / 32 * 32; }
+
+extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t* labels, const float* row_scale,
+                             int64_t N, int H, int V, int64_t pad_id, int with_grad, int accumulate_w,
+                             float* workspace, int chunk_rows,
+                             float* tok_nll, float* lse, float* dh, float* dW, float* db, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAED_CHECK_ARG(N >= 0 && H > 0 && V > 0 && chunk_rows > 0, "proj_nll: bad size");
+    if (N == 0) return 0;
+    LAED_CHECK_ARG(h && W && labels && workspace && tok_nll, "proj_nll: null pointer");
+    LAED_CHECK_ARG(!with_grad || (dh && dW && db), "proj_nll: with_grad needs dh, dW, db");
+    LAED_CHECK_ARG(aligned16(workspace), "proj_nll: workspace must be 16-byte aligned");
+    const int64_t ldl = laed_proj_nll_ldl(V);
+    bool acc = accumulate_w != 0;
+    for (int64_t r0 = 0; r0 < N; r0 += chunk_rows) {
+        const int rows = (int)((N - r0) < chunk_rows ? (N - r0) : chunk_rows);
+        const float* hc = h + r0 * H;
+        LAED_TRY(laed_sgemm_impl(false, true, rows, V, H, hc, H, W, H, workspace, ldl, b, false, nullptr, false, stream));
+        if (with_grad)
+            hipLaunchKernelGGL((proj_rows_kernel<MODE_GRAD>), dim3(rows_grid(rows)), dim3(256), 0, stream, workspace, (int64_t)rows, V,
+                               ldl, labels + r0, row_scale ? row_scale + r0 : nullptr, pad_id, tok_nll + r0, lse ? lse + r0 : nullptr);
+        else
+            hipLaunchKernelGGL((proj_rows_kernel<MODE_STATS>), dim3(rows_grid(rows)), dim3(256), 0, stream, workspace, (int64_t)rows, V,
+                               ldl, labels + r0, nullptr, pad_id, tok_nll + r0, lse ? lse + r0 : nullptr);
+        LAED_LAUNCH_CHECK("proj_rows");
+        if (with_grad) {
+            LAED_TRY(laed_sgemm_impl(false, false, rows, H, V, workspace, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
+            LAED_TRY(laed_sgemm_impl(true, false, V, H, rows, workspace, ldl, hc, H, dW, H, nullptr, acc, db, acc, stream));
+            acc = true;
+        }
+    }
+    return 0;
+}
+
+extern "C" int laed_log_softmax_rows(float* logits, int64_t N, int V, int ldl, float* lse, void* stream) {
+    LAED_CHECK_ARG(N >= 0 && V > 0 && ldl >= V && ldl % 4 == 0, "log_softmax_rows: bad size (ldl must be a multiple of 4)");
+    if (N == 0) return 0;
+    LAED_CHECK_ARG(logits && aligned16(logits), "log_softmax_rows: null or unaligned pointer");
+    hipLaunchKernelGGL((proj_rows_kernel<MODE_LOGP>), dim3(rows_grid(N)), dim3(256), 0, (hipStream_t)stream, logits, N, V,
+                       (int64_t)ldl, (const int64_t*)nullptr, (const float*)nullptr, (int64_t)-1, (float*)nullptr, lse);
+    LAED_LAUNCH_CHECK("log_softmax_rows");
+    return 0;
+}
+
+extern "C" int laed_argmax_rows(const float* logits, int64_t N, int V, int ldl, int64_t* ids, void* stream) {
+    LAED_CHECK_ARG(N >= 0 && V > 0 && ldl >= V, "argmax_rows: bad size");
+    if (N == 0) return 0;
+    LAED_CHECK_ARG(logits && ids, "argmax_rows: null pointer");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows_grid(N)), dim3(256), 0, (hipStream_t)stream, logits, N, V, (int64_t)ldl, ids);
+    LAED_LAUNCH_CHECK("argmax_rows");
+    return 0;
+}
+
+extern "C" int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int64_t N, int64_t pad_id, float* out, void* stream) {
+    LAED_CHECK_ARG(N >= 0, "nll_reduce: bad size");
+    LAED_CHECK_ARG(tok_nll && labels && out, "nll_reduce: null pointer");
+    hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tok_nll, labels, N, pad_id, out);
+    LAED_LAUNCH_CHECK("nll_reduce");
+    return 0;
+}
+
+extern "C" int laed_dot(const float* a, const float* b, int64_t n, float* out, void* stream) {
+    LAED_CHECK_ARG(n >= 0, "dot: bad size");
+    LAED_CHECK_ARG(a && b && out, "dot: null pointer");
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, out);
+    LAED_LAUNCH_CHECK("dot");
+    return 0;
+}

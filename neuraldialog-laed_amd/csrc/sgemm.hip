@@ -1,0 +1,291 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TF peak).
+//
+//   C[M,N] = op(A) * op(B) (+ bias[N]) (+ C)          all row-major, arbitrary leading dimensions
+//
+// Block = 256 threads = 4 waves (2 x 2); block tile BM x BN (128x128 or 64x64), K step 32.
+// Both operands are staged in LDS as [k][row] (row contiguous, +pad) whatever their layout in HBM, so the
+// MFMA fragment read is one conflict-free ds_read_b32 per operand per instruction:
+//   lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]   (guide section 3, f32 32x32x2 map)
+// HBM -> registers -> LDS double buffering: the next K tile's global loads are issued before the MFMA block
+// of the current tile and written to the other LDS buffer after it; one barrier per K tile.
+// Edge tiles are zero-filled on load and masked on store, so any M, N, K works; 16-byte vector loads are
+// used when base pointers and leading dimensions allow (VEC), scalar loads otherwise.
+// blockIdx -> tile: XCD-aware remap (blocks b, b+8, ... share an XCD/L2) then grouped (8 row tiles) ordering,
+// so the blocks resident on one XCD at a time share A row panels and walk the same B column panels.
+#include "laed_common.h"
+
+namespace {
+
+struct SgemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    float* colsum;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int accumulate, colsum_acc;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+// Load a (BR rows) x (BK k) tile into registers as float4s.
+//  KCONTIG: element (r,k) at P[r*ld + k]   -> each thread takes 4 consecutive k of one row
+// !KCONTIG: element (r,k) at P[k*ld + r]   -> each thread takes 4 consecutive rows of one k
+template <bool KCONTIG, int BR, bool VEC>
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int r0, int k0, int R, int K,
+                                          int tid, float4 (&reg)[BR * BK / 4 / NT]) {
+    constexpr int NL = BR * BK / 4 / NT;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int idx = tid + i * NT;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KCONTIG) {
+            int row = idx / (BK / 4), kq = idx % (BK / 4);
+            int gr = r0 + row, gk = k0 + 4 * kq;
+            if (gr < R && gk < K) {
+                const float* src = P + (int64_t)gr * ld + gk;
+                if (VEC && gk + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (gk + 1 < K) v.y = src[1];
+                    if (gk + 2 < K) v.z = src[2];
+                    if (gk + 3 < K) v.w = src[3];
+                }
+            }
+        } else {
+            int k = idx / (BR / 4), rq = idx % (BR / 4);
+            int gk = k0 + k, gr = r0 + 4 * rq;
+            if (gk < K && gr < R) {
+                const float* src = P + (int64_t)gk * ld + gr;
+                if (VEC && gr + 3 < R) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (gr + 1 < R) v.y = src[1];
+                    if (gr + 2 < R) v.z = src[2];
+                    if (gr + 3 < R) v.w = src[3];
+                }
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+// Write the registers to the LDS image s[BK][S], S = BR + pad (pad 1 for KCONTIG: conflict-free transposing
+// b32 writes; pad 4 otherwise: 16-byte aligned b128 writes).
+template <bool KCONTIG, int BR>
+__device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const float4 (&reg)[BR * BK / 4 / NT]) {
+    constexpr int NL = BR * BK / 4 / NT;
+    constexpr int S = BR + (KCONTIG ? 1 : 4);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int idx = tid + i * NT;
+        if (KCONTIG) {
+            int row = idx / (BK / 4), kq = idx % (BK / 4);
+            float* d = s + (4 * kq) * S + row;
+            d[0] = reg[i].x;
+            d[S] = reg[i].y;
+            d[2 * S] = reg[i].z;
+            d[3 * S] = reg[i].w;
+        } else {
+            int k = idx / (BR / 4), rq = idx % (BR / 4);
+            *reinterpret_cast<float4*>(s + k * S + 4 * rq) = reg[i];
+        }
+    }
+}
+
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
+    constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
+    constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
+    constexpr int SA = BM + (AK ? 1 : 4);
+    constexpr int SB = BN + (BKC ? 1 : 4);
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NLA = BM * BK / 4 / NT, NLB = BN * BK / 4 / NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                 // [2][BK][SA]
+    float* sB = smem + 2 * BK * SA;   // [2][BK][SB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap (bijective for any grid size), then grouped ordering over row tiles
+    int nwg = gridDim.x, pid = blockIdx.x;
+    int xcd = pid & 7, q = nwg >> 3, r = nwg & 7;
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+    constexpr int GROUP_M = 8;
+    int in_group = GROUP_M * p.tiles_n;
+    int gid = wg / in_group, first_m = gid * GROUP_M;
+    int gsz = min(p.tiles_m - first_m, GROUP_M);
+    int tile_m = first_m + (wg % in_group) % gsz;
+    int tile_n = (wg % in_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[NLA], rb[NLB];
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
+
+    const int nkt = (p.K + BK - 1) / BK;
+    tile_load<AK, BM, VEC>(p.A, p.lda, m0, 0, p.M, p.K, tid, ra);
+    tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+    if (TA && do_colsum) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+    }
+    tile_store<AK, BM>(sA, tid, ra);
+    tile_store<BKC, BN>(sB, tid, rb);
+    __syncthreads();
+
+    int cur = 0;
+    const int lrow = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if (more) {
+            tile_load<AK, BM, VEC>(p.A, p.lda, m0, (kt + 1) * BK, p.M, p.K, tid, ra);
+            tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, (kt + 1) * BK, p.N, p.K, tid, rb);
+        }
+        const float* a_s = sA + cur * BK * SA + wm * (BM / 2) + lrow;
+        const float* b_s = sB + cur * BK * SB + wn * (BN / 2) + lrow;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int krow = 2 * kk + lk;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_s[krow * SA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_s[krow * SB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            if (TA && do_colsum) {
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+            }
+            tile_store<AK, BM>(sA + (cur ^ 1) * BK * SA, tid, ra);
+            tile_store<BKC, BN>(sB + (cur ^ 1) * BK * SB, tid, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C/D map  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + lrow;
+            const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row < p.M && col < p.N) {
+                    float* dst = p.C + (int64_t)row * p.ldc + col;
+                    float v = acc[i][j][e] + bv;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+
+    // ---- optional column sums of A (TA only): colsum[m] = sum_k A[k][m]
+    if (TA) {
+        if (do_colsum) {   // block-uniform
+            // every load of this thread has the same rq = tid % (BM/4); NT/(BM/4) threads share an rq
+            constexpr int RQ = BM / 4, G = NT / RQ;
+            float* red = smem;   // reuse (all waves passed the final barrier of the main loop)
+            const int rq = tid % RQ, g = tid / RQ;
+            red[(g * RQ + rq) * 4 + 0] = csum.x;
+            red[(g * RQ + rq) * 4 + 1] = csum.y;
+            red[(g * RQ + rq) * 4 + 2] = csum.z;
+            red[(g * RQ + rq) * 4 + 3] = csum.w;
+            __syncthreads();
+            if (tid < BM) {
+                float s = 0.f;
+#pragma unroll
+                for (int gg = 0; gg < G; ++gg) s += red[(gg * RQ + (tid >> 2)) * 4 + (tid & 3)];
+                const int m = m0 + tid;
+                if (m < p.M) p.colsum[m] = p.colsum_acc ? p.colsum[m] + s : s;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
+    constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
+    constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
+    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC>;
+    static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return laed_fail((int)e, "sgemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    SgemmArgs p = a;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = (a.N + BN - 1) / BN;
+    int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, p);
+    LAED_LAUNCH_CHECK("sgemm");
+    return 0;
+}
+
+template <bool TA, bool TB>
+int launch_layout(const SgemmArgs& a, bool vec, hipStream_t stream) {
+    const int64_t big_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool big = big_tiles >= 192;   // enough 128x128 tiles to occupy most of the 256 CUs
+    if (big) return vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
+    return vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
+}
+
+}   // namespace
+
+int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, bool accumulate,
+                    float* colsum_a, bool colsum_accumulate, hipStream_t stream) {
+    LAED_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sgemm: negative dimension");
+    if (M == 0 || N == 0) return 0;
+    LAED_CHECK_ARG(A && B && C, "sgemm: null matrix pointer");
+    LAED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sgemm: leading dimension too small");
+    LAED_CHECK_ARG(!(transA && transB), "sgemm: transA && transB not supported");
+    LAED_CHECK_ARG(colsum_a == nullptr || transA, "sgemm: colsum_a needs transA");
+    SgemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.colsum = colsum_a;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K;
+    a.accumulate = accumulate ? 1 : 0;
+    a.colsum_acc = colsum_accumulate ? 1 : 0;
+    a.tiles_m = a.tiles_n = 0;
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    if (!transA && transB) return launch_layout<false, true>(a, vec, stream);
+    if (!transA && !transB) return launch_layout<false, false>(a, vec, stream);
+    return launch_layout<true, false>(a, vec, stream);
+}
+
+extern "C" int laed_sgemm(int transA, int transB, int M, int N, int K,
+                          const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, const float* bias, int accumulate,
+                          float* colsum_a, int colsum_accumulate, void* stream) {
+    return laed_sgemm_impl(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate != 0,
+                           colsum_a, colsum_accumulate != 0, (hipStream_t)stream);
+}

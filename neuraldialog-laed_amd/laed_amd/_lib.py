@@ -1,0 +1,85 @@
+"""ctypes binding of liblaed_hip.so (the C ABI declared in include/laed_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, import fails loudly with the build command.
+All wrappers take torch CUDA tensors, check dtype/contiguity on the host, and enqueue on torch's current stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblaed_hip.so")
+
+if not os.path.exists(_SO):
+    raise ImportError(
+        "laed_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C neuraldialog-laed_amd/csrc` (hipcc, --offload-arch=gfx950). "
+        "There is no CPU fallback for this package." % _SO)
+
+lib = ctypes.CDLL(_SO)
+
+_i, _i64, _f, _d, _p, _u64 = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p,
+                              ctypes.c_uint64)
+
+_SIGS = {
+    "laed_version": ([], _i),
+    "laed_last_error": ([], ctypes.c_char_p),
+    "laed_sgemm": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p], _i),
+    "laed_embed_gather": ([_p, _i64, _p, _i, _i, _p, _f, _p, _p], _i),
+    "laed_embed_scatter_add": ([_p, _i64, _p, _i, _i, _p, _f, _i64, _p, _p], _i),
+    "laed_dropout_keep_mask": ([_p, _i64, _f, _u64, _u64, _p], _i),
+    "laed_uniform": ([_p, _i64, _u64, _u64, _p], _i),
+    "laed_gru_fwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p], _i),
+    "laed_gru_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p], _i),
+    "laed_gumbel_latent_fwd": ([_p, _p, _i64, _i, _f, _i, _p, _p, _p, _p], _i),
+    "laed_gumbel_latent_bwd": ([_p, _p, _p, _p, _i64, _i, _f, _p, _p], _i),
+    "laed_latent_stats_blocks": ([], _i),
+    "laed_latent_stats": ([_p, _i64, _i, _i, _p, _p, _p], _i),
+    "laed_latent_finalize": ([_p, _d, _i, _i, _p, _p, _p], _i),
+    "laed_latent_bwd": ([_p, _p, _p, _i, _i64, _d, _i, _i, _p, _i, _p], _i),
+    "laed_proj_nll_ldl": ([_i], _i),
+    "laed_proj_nll": ([_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p], _i),
+    "laed_log_softmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
+    "laed_argmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
+    "laed_nll_reduce": ([_p, _p, _i64, _i64, _p, _p], _i),
+    "laed_adam_step": ([_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _f, _p], _i),
+    "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),
+    "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),
+    "laed_dot": ([_p, _p, _i64, _p, _p], _i),
+    "laed_gru_decode_greedy": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p], _i),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+for _name, (_args, _res) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = _res
+
+
+class LaedError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib.laed_last_error()
+        raise LaedError("%s failed with status %d: %s" % (what, status, msg.decode() if msg else ""))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LaedError("laed_amd kernels need CUDA (ROCm) tensors; got a CPU tensor")
+    if t.dtype != dtype:
+        raise LaedError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise LaedError("expected a contiguous tensor, got strides %s for shape %s" % (t.stride(), tuple(t.shape)))
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,344 @@
+"""Host-side operators over the C ABI: thin checked wrappers + torch.autograd.Function glue.
+
+Everything here runs on the HIP kernels of liblaed_hip.so; torch is used for device memory, streams and
+the autograd tape only.  Sequence tensors are time-major ([T,B,*]) at this level.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+I64 = torch.int64
+U8 = torch.uint8
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# raw wrappers
+# ----------------------------------------------------------------------------------------------
+def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, colsum_out=None,
+          colsum_accumulate=False):
+    """C = op(A) op(B) (+bias) (+C).  A, B 2-D fp32 (row stride arbitrary, unit column stride)."""
+    assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N = B.shape[0] if transB else B.shape[1]
+    Kb = B.shape[1] if transB else B.shape[0]
+    if K != Kb:
+        raise _lib.LaedError("sgemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    import ctypes
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    for t in (A, B, out, bias, colsum_out):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise _lib.LaedError("sgemm: operands must be fp32 CUDA tensors")
+    check(lib.laed_sgemm(int(transA), int(transB), M, N, K, vp(A), A.stride(0) if A.shape[0] > 1 else max(A.shape[1], 1),
+                         vp(B), B.stride(0) if B.shape[0] > 1 else max(B.shape[1], 1),
+                         vp(out), out.stride(0) if out.shape[0] > 1 else max(N, 1), vp(bias), int(accumulate),
+                         vp(colsum_out), int(colsum_accumulate), stream()), "laed_sgemm")
+    return out
+
+
+def uniform(n, seed, offset, device):
+    u = torch.empty(n, device=device, dtype=torch.float32)
+    check(lib.laed_uniform(ptr(u), n, seed, offset, stream()), "laed_uniform")
+    return u
+
+
+def dropout_keep_mask(n, p, seed, offset, device):
+    keep = torch.empty(n, device=device, dtype=U8)
+    check(lib.laed_dropout_keep_mask(ptr(keep, U8), n, float(p), seed, offset, stream()), "laed_dropout_keep_mask")
+    return keep
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    check(lib.laed_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), int(step), lr, beta1, beta2, eps,
+                             float(grad_scale), stream()), "laed_adam_step")
+
+
+def nll_reduce(tok_nll, labels, pad_id):
+    out = torch.empty(2, device=tok_nll.device, dtype=torch.float32)
+    check(lib.laed_nll_reduce(ptr(tok_nll), ptr(labels, I64), tok_nll.numel(), int(pad_id), ptr(out), stream()),
+          "laed_nll_reduce")
+    return out
+
+
+def proj_ldl(V):
+    return int(lib.laed_proj_nll_ldl(int(V)))
+
+
+_WS = {}
+
+
+def workspace(key, numel, device):
+    """Reusable fp32 scratch (grown on demand, one per key/device); contents are undefined between calls."""
+    k = (key, device)
+    t = _WS.get(k)
+    if t is None or t.numel() < numel:
+        t = torch.empty(numel, device=device, dtype=torch.float32)
+        _WS[k] = t
+    return t
+
+
+def proj_chunk_rows(N, V):
+    """Rows per logits chunk: ~1 GiB of workspace at most, at least 1024 rows."""
+    ldl = proj_ldl(V)
+    rows = max(1024, (1 << 28) // ldl)
+    rows = (rows // 128) * 128
+    return int(min(max(N, 1), rows))
+
+
+def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None):
+    N, H = h.shape
+    V = W.shape[0]
+    dev = h.device
+    if chunk_rows is None:
+        chunk_rows = proj_chunk_rows(N, V)
+    ws = workspace("proj", chunk_rows * proj_ldl(V), dev)
+    tok = torch.empty(N, device=dev, dtype=torch.float32)
+    lse = torch.empty(N, device=dev, dtype=torch.float32)
+    dh = dW = db = None
+    if with_grad:
+        dh = torch.empty_like(h)
+        dW = torch.empty_like(W)
+        db = torch.empty(V, device=dev, dtype=torch.float32)
+    check(lib.laed_proj_nll(ptr(h), ptr(W), ptr(b), ptr(labels, I64), ptr(row_scale), N, H, V, int(pad_id),
+                            int(with_grad), 0, ptr(ws), int(chunk_rows), ptr(tok), ptr(lse), ptr(dh), ptr(dW), ptr(db),
+                            stream()), "laed_proj_nll")
+    return tok, lse, dh, dW, db
+
+
+def logits_rows(h, W, b):
+    """[N, ldl] logits buffer (fresh allocation, only for callers that want the full tensor)."""
+    N = h.shape[0]
+    V = W.shape[0]
+    ldl = proj_ldl(V)
+    buf = torch.empty((N, ldl), device=h.device, dtype=torch.float32)
+    sgemm(h, W, transB=True, bias=b, out=buf[:, :V])
+    return buf
+
+
+def log_softmax_rows_(buf, V):
+    N, ldl = buf.shape
+    check(lib.laed_log_softmax_rows(ptr(buf), N, V, ldl, None, stream()), "laed_log_softmax_rows")
+    return buf
+
+
+def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_id):
+    B, H = h0.shape
+    V, E = emb.shape
+    dev = h0.device
+    hbuf = torch.empty((max_len + 1, B, H), device=dev, dtype=torch.float32)
+    xbuf = torch.empty((B, E), device=dev, dtype=torch.float32)
+    gates = torch.empty((B, 3 * H), device=dev, dtype=torch.float32)
+    logits = torch.empty((B, proj_ldl(V)), device=dev, dtype=torch.float32)
+    ids = torch.empty((max_len + 1, B), device=dev, dtype=I64)
+    check(lib.laed_gru_decode_greedy(ptr(emb), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(proj_w), ptr(proj_b),
+                                     ptr(h0), B, E, H, V, int(max_len), int(go_id), ptr(hbuf), ptr(xbuf), ptr(gates),
+                                     ptr(logits), ptr(ids, I64), stream()), "laed_gru_decode_greedy")
+    return ids[1:], hbuf
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd glue
+# ----------------------------------------------------------------------------------------------
+class EmbedFunction(torch.autograd.Function):
+    """out[rows,E] = weight[ids] (* keep/(1-p)); PAD rows get no gradient."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, keep, drop_p, pad_id):
+        rows = ids.numel()
+        V, E = weight.shape
+        out = torch.empty((rows, E), device=weight.device, dtype=torch.float32)
+        check(lib.laed_embed_gather(ptr(ids, I64), rows, ptr(weight), V, E, ptr(keep, U8) if keep is not None else None,
+                                    float(drop_p), ptr(out), stream()), "laed_embed_gather")
+        ctx.save_for_backward(ids, keep)
+        ctx.meta = (V, E, float(drop_p), int(pad_id))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, keep = ctx.saved_tensors
+        V, E, p, pad_id = ctx.meta
+        dout = _f32c(dout)
+        dw = torch.zeros((V, E), device=dout.device, dtype=torch.float32)
+        check(lib.laed_embed_scatter_add(ptr(ids, I64), ids.numel(), ptr(dout), V, E,
+                                         ptr(keep, U8) if keep is not None else None, p, pad_id, ptr(dw), stream()),
+              "laed_embed_scatter_add")
+        return dw, None, None, None, None
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = x W^T + b on the fp32 MFMA GEMM; backward = two more GEMMs (+ bias grad as a column sum)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = _f32c(x)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return sgemm(x, W, transB=True, bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = sgemm(dy, W) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or ctx.has_bias:
+            db = torch.empty(W.shape[0], device=W.device, dtype=torch.float32) if ctx.has_bias else None
+            dW = sgemm(dy, x, transA=True, colsum_out=db)
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    return LinearFunction.apply(x, W, b)
+
+
+class GRUFunction(torch.autograd.Function):
+    """x[T,B,E] (time-major) -> out[T,B,H], hT[B,H]."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0):
+        x = _f32c(x)
+        T, B, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        hbuf = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
+        gates = torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32)
+        hn = torch.empty((T, B, H), device=dev, dtype=torch.float32)
+        h0c = _f32c(h0) if h0 is not None else None
+        check(lib.laed_gru_fwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(h0c), T, B, E, H,
+                               ptr(hbuf), ptr(gates), ptr(hn), stream()), "laed_gru_fwd")
+        ctx.save_for_backward(x, w_ih, w_hh, hbuf, gates, hn)
+        ctx.has_h0 = h0 is not None
+        out = hbuf[1:]
+        hT = hbuf[T]
+        return out, hT
+
+    @staticmethod
+    def backward(ctx, dout, dhT):
+        x, w_ih, w_hh, hbuf, gates, hn = ctx.saved_tensors
+        T, B, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        dout = _f32c(dout) if dout is not None else None
+        dhT = _f32c(dhT) if dhT is not None else None
+        dgh = workspace("gru_dgh", T * B * 3 * H, dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw_ih = torch.empty_like(w_ih)
+        dw_hh = torch.empty_like(w_hh)
+        db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)
+        db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
+        dh0 = torch.empty((B, H), device=dev, dtype=torch.float32)
+        # NOTE: overwrites the saved `gates` (r,z,n -> d gi): the tape is single-use, like cuDNN's reserve space
+        check(lib.laed_gru_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(hbuf), ptr(gates), ptr(hn), ptr(dout), ptr(dhT),
+                               T, B, E, H, ptr(dgh), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), 0,
+                               stream()), "laed_gru_bwd")
+        return dx, dw_ih, dw_hh, db_ih, db_hh, (dh0 if ctx.has_h0 else None)
+
+
+class GumbelLatentFunction(torch.autograd.Function):
+    """logits[R,k], u[R,k] -> y (Gumbel-softmax sample or one-hot), log_qy = log_softmax(logits), ids[R]."""
+
+    @staticmethod
+    def forward(ctx, logits, u, tau, hard):
+        logits = _f32c(logits)
+        R, k = logits.shape
+        y = torch.empty_like(logits)
+        log_qy = torch.empty_like(logits)
+        ids = torch.empty(R, device=logits.device, dtype=I64)
+        check(lib.laed_gumbel_latent_fwd(ptr(logits), ptr(_f32c(u)), R, k, float(tau), int(bool(hard)), ptr(y), ptr(ids, I64),
+                                         ptr(log_qy), stream()), "laed_gumbel_latent_fwd")
+        ctx.save_for_backward(y, log_qy)
+        ctx.meta = (float(tau), bool(hard))
+        ctx.mark_non_differentiable(ids)
+        return y, log_qy, ids
+
+    @staticmethod
+    def backward(ctx, dy, dlog_qy, _dids):
+        y, log_qy = ctx.saved_tensors
+        tau, hard = ctx.meta
+        R, k = y.shape
+        dy = None if (hard or dy is None) else _f32c(dy)          # the hard one-hot carries no gradient
+        dlq = _f32c(dlog_qy) if dlog_qy is not None else None
+        dlogits = torch.empty_like(y)
+        check(lib.laed_gumbel_latent_bwd(ptr(y), ptr(dy), ptr(log_qy), ptr(dlq), R, k, tau, ptr(dlogits), stream()),
+              "laed_gumbel_latent_bwd")
+        return dlogits, None, None, None
+
+
+class LatentLossFunction(torch.autograd.Function):
+    """log_qy[B*y,k] -> (bpr, mi, row_kl) 0-dim tensors; batch statistics are all-reduced over `group`."""
+
+    @staticmethod
+    def forward(ctx, log_qy, y_size, k, group):
+        log_qy = _f32c(log_qy)
+        dev = log_qy.device
+        B = log_qy.shape[0] // y_size
+        nblk = int(lib.laed_latent_stats_blocks())
+        ws = workspace("latent", nblk * (y_size * k + 2), dev)
+        stats = torch.empty(y_size * k + 2, device=dev, dtype=torch.float32)
+        check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
+        Bg = float(B)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(stats, group=group)
+            Bg = float(B * dist.get_world_size(group))       # equal shards per rank
+        scal = torch.empty(4, device=dev, dtype=torch.float32)
+        coef = torch.empty(y_size * k, device=dev, dtype=torch.float32)
+        check(lib.laed_latent_finalize(ptr(stats), Bg, y_size, k, ptr(scal), ptr(coef), stream()), "laed_latent_finalize")
+        ctx.save_for_backward(log_qy, coef)
+        ctx.meta = (B, Bg, y_size, k)
+        return scal[0], scal[1], scal[2]
+
+    @staticmethod
+    def backward(ctx, d_bpr, d_mi, d_rowkl):
+        # mi is a logged quantity only (sent_models.py:155-158): no gradient path is provided for it.
+        log_qy, coef = ctx.saved_tensors
+        B, Bg, y_size, k = ctx.meta
+        dlq = None
+        for g, mutual in ((d_bpr, 1), (d_rowkl, 0)):
+            if g is None:
+                continue
+            g = _f32c(g).reshape(1)
+            first = dlq is None
+            if first:
+                dlq = torch.empty_like(log_qy)
+            check(lib.laed_latent_bwd(ptr(log_qy), ptr(coef), ptr(g), mutual, B, Bg, y_size, k, ptr(dlq), int(not first),
+                                      stream()), "laed_latent_bwd")
+        return dlq, None, None, None
+
+
+class ProjNLLFunction(torch.autograd.Function):
+    """h[N,H], W[V,H], b[V], labels[N], row_scale[N] -> (loss = sum_r row_scale[r]*nll[r], tok_nll[N]).
+
+    Forward and backward GEMMs run in ONE fused pass per row chunk (the gradients for d loss = 1 are produced
+    while the logits chunk is still in the workspace); backward only rescales them by the incoming gradient.
+    """
+
+    @staticmethod
+    def forward(ctx, h, W, b, labels, row_scale, pad_id):
+        h = _f32c(h)
+        with_grad = any(ctx.needs_input_grad[:3])
+        tok, lse, dh, dW, db = proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad)
+        loss = torch.empty(1, device=h.device, dtype=torch.float32)
+        check(lib.laed_dot(ptr(tok), ptr(row_scale), tok.numel(), ptr(loss), stream()), "laed_dot")
+        loss = loss[0]
+        if with_grad:
+            ctx.save_for_backward(dh, dW, db)
+        ctx.mark_non_differentiable(tok)
+        return loss, tok
+
+    @staticmethod
+    def backward(ctx, dloss, _dtok):
+        dh, dW, db = ctx.saved_tensors
+        g = _f32c(dloss).reshape(1)
+        for t in (dh, dW, db):
+            check(lib.laed_scale_by_dev(ptr(t), ptr(t), ptr(g), t.numel(), stream()), "laed_scale_by_dev")
+        return dh, dW, db, None, None, None

@@ -1,0 +1,266 @@
+"""GPU parity tests of every C-ABI kernel against the CPU oracle / plain torch-CPU fp32 math.
+
+All calls go through liblaed_hip.so (ctypes).  Tolerances: fp32 MFMA is an exact fp32 fma chain, so results
+differ from the CPU only by summation order: 1e-5 relative on GEMM-shaped outputs, 1e-4 after recurrences.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from laed_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import laed_oracle
+    return laed_oracle
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 50, 33), (128, 128, 32), (300, 200, 129), (1170, 1000, 512), (2048, 2304, 200),
+                                   (1, 7, 5), (33, 1, 64)])
+def test_sgemm_layouts(ops, M, N, K):
+    for (tA, tB) in ((False, True), (False, False), (True, False)):
+        A = rnd(K, M, seed=1) if tA else rnd(M, K, seed=1)
+        B = rnd(N, K, seed=2) if tB else rnd(K, N, seed=2)
+        bias = rnd(N, seed=3)
+        ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double() + bias.double()
+        out = ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, bias=dev(bias))
+        assert rel_err(out.cpu(), ref) < 2e-6, (tA, tB)
+        # accumulate + column sums of A (transposed-A layout only)
+        C0 = rnd(M, N, seed=4)
+        Cd = dev(C0.clone())
+        cs = dev(torch.ones(M)) if tA else None
+        ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, out=Cd, accumulate=True, colsum_out=cs, colsum_accumulate=True)
+        assert rel_err(Cd.cpu(), ref - bias.double() + C0.double()) < 2e-6
+        if tA:
+            assert rel_err(cs.cpu(), A.double().sum(0) + 1.0) < 2e-6
+
+
+def test_sgemm_unaligned_views(ops):
+    # leading dimensions that are not multiples of 4 and 4-byte-aligned bases -> scalar-load kernels
+    A = rnd(90, 71, seed=5)
+    B = rnd(60, 71, seed=6)
+    Ad, Bd = dev(A), dev(B)
+    out = ops.sgemm(Ad[1:, 1:], Bd[:, 1:], transB=True)
+    assert rel_err(out.cpu(), A[1:, 1:].double() @ B[:, 1:].double().t()) < 2e-6
+    outbuf = dev(torch.zeros(89, 75))
+    ops.sgemm(Ad[1:, 1:], Bd[:, 1:], transB=True, out=outbuf[:, 3:63])
+    assert rel_err(outbuf[:, 3:63].cpu(), A[1:, 1:].double() @ B[:, 1:].double().t()) < 2e-6
+    assert float(outbuf[:, :3].abs().sum()) == 0.0 and float(outbuf[:, 63:].abs().sum()) == 0.0
+
+
+def test_sgemm_bad_args(ops):
+    from laed_amd._lib import LaedError
+    with pytest.raises(LaedError):
+        ops.sgemm(dev(rnd(4, 5)), dev(rnd(6, 7)))
+    with pytest.raises(LaedError):
+        ops.sgemm(rnd(4, 5), rnd(5, 7))          # CPU tensors are refused: no CPU fallback
+
+
+def _gru_case(ops, O, T, B, E, H, with_h0, seed, tol):
+    x = rnd(T, B, E, seed=seed)
+    k = 1.0 / np.sqrt(H)
+    w_ih, w_hh = rnd(3 * H, E, seed=seed + 1, scale=k), rnd(3 * H, H, seed=seed + 2, scale=k)
+    b_ih, b_hh = rnd(3 * H, seed=seed + 3, scale=k), rnd(3 * H, seed=seed + 4, scale=k)
+    h0 = rnd(B, H, seed=seed + 5) if with_h0 else None
+    wout, whT = rnd(T, B, H, seed=seed + 6), rnd(B, H, seed=seed + 7)
+    # oracle (batch-first) with autograd
+    cp = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    ch0 = h0.clone().requires_grad_(True) if with_h0 else torch.zeros(B, H)
+    out_c, hT_c = O.gru_seq(cp[0].transpose(0, 1), ch0, cp[1], cp[2], cp[3], cp[4])
+    ((out_c.transpose(0, 1) * wout).sum() + (hT_c * whT).sum()).backward()
+    # HIP
+    gp = [dev(t).requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    gh0 = dev(h0).requires_grad_(True) if with_h0 else None
+    out_g, hT_g = ops.GRUFunction.apply(gp[0], gp[1], gp[2], gp[3], gp[4], gh0)
+    assert rel_err(out_g.detach().cpu(), out_c.detach().transpose(0, 1)) < tol
+    assert rel_err(hT_g.detach().cpu(), hT_c.detach()) < tol
+    ((out_g * dev(wout)).sum() + (hT_g * dev(whT)).sum()).backward()
+    for a, b, name in zip(gp, cp, ("dx", "dw_ih", "dw_hh", "db_ih", "db_hh")):
+        assert rel_err(a.grad.cpu(), b.grad) < 10 * tol, name
+    if with_h0:
+        assert rel_err(gh0.grad.cpu(), ch0.grad) < 10 * tol
+
+
+@pytest.mark.parametrize("T,B,E,H,with_h0", [(5, 6, 16, 32, False), (7, 40, 20, 48, True), (4, 200, 64, 96, True),
+                                             (40, 30, 200, 512, True), (3, 130, 36, 160, False)])
+def test_gru_fwd_bwd(ops, O, T, B, E, H, with_h0):
+    _gru_case(ops, O, T, B, E, H, with_h0, seed=10, tol=1e-5)
+
+
+def test_gru_all_tile_configs(ops, O):
+    # the block-tile choice is a pure launch-geometry decision: every forced config must agree
+    try:
+        for wm in ("4", "2", "1"):
+            os.environ["LAED_GRU_WM"] = wm
+            _gru_case(ops, O, 3, 260, 32, 64, True, seed=20, tol=1e-5)
+            _gru_case(ops, O, 2, 5, 8, 40, False, seed=21, tol=1e-5)
+    finally:
+        os.environ.pop("LAED_GRU_WM", None)
+
+
+def test_gumbel_latent(ops, O):
+    for (R, k, tau, seed) in ((12, 5, 1.0, 1), (600, 10, 1.0, 2), (77, 20, 0.5, 3), (9, 40, 2.0, 4)):
+        logits = rnd(R, k, seed=seed, scale=2.0)
+        u = torch.rand(R, k, generator=torch.Generator().manual_seed(seed))
+        wy, wl = rnd(R, k, seed=seed + 50), rnd(R, k, seed=seed + 60)
+        lc = logits.clone().requires_grad_(True)
+        y_c, ids_c = O.gumbel_softmax(lc, u, tau, hard=False)
+        lq_c = torch.log_softmax(lc, dim=1)
+        ((y_c * wy).sum() + (lq_c * wl).sum()).backward()
+        lg = dev(logits).requires_grad_(True)
+        y_g, lq_g, ids_g = ops.GumbelLatentFunction.apply(lg, dev(u), tau, False)
+        assert rel_err(y_g.detach().cpu(), y_c.detach()) < 2e-6
+        assert rel_err(lq_g.detach().cpu(), lq_c.detach()) < 2e-6
+        assert np.array_equal(ids_g.cpu().numpy(), ids_c.view(-1).numpy())
+        ((y_g * dev(wy)).sum() + (lq_g * dev(wl)).sum()).backward()
+        assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5
+        y_h, _, ids_h = ops.GumbelLatentFunction.apply(dev(logits), dev(u), tau, True)
+        yh_c, idh_c = O.gumbel_softmax(logits, u, tau, hard=True)
+        assert np.array_equal(y_h.cpu().numpy(), yh_c.numpy()) and np.array_equal(ids_h.cpu().numpy(), idh_c.view(-1).numpy())
+
+
+def test_latent_losses(ops, O):
+    for (B, y, k, seed) in ((6, 4, 5, 1), (30, 20, 10, 2), (300, 20, 10, 3), (5, 3, 40, 4)):
+        log_qy = torch.log_softmax(rnd(B * y, k, seed=seed, scale=3.0), dim=1)
+        for use_mutual in (True, False):
+            lc = log_qy.clone().requires_grad_(True)
+            reg_c, bpr_c, mi_c = O.latent_losses(lc, y, k, use_mutual)
+            (reg_c * 1.7).backward()
+            lg = dev(log_qy).requires_grad_(True)
+            bpr_g, mi_g, rowkl_g = ops.LatentLossFunction.apply(lg, y, k, None)
+            reg_g = bpr_g if use_mutual else rowkl_g
+            assert abs(float(reg_g) - float(reg_c)) <= 1e-7 + 1e-5 * abs(float(reg_c))
+            assert abs(float(bpr_g) - float(bpr_c)) <= 1e-7 + 1e-5 * abs(float(bpr_c))
+            assert abs(float(mi_g) - float(mi_c)) <= 2e-6 + 1e-4 * abs(float(mi_c))   # difference of two entropies
+            (reg_g * 1.7).backward()
+            assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5
+
+
+@pytest.mark.parametrize("N,H,V,chunk", [(48, 32, 50, None), (100, 64, 401, 32), (1170, 128, 1003, 512), (300, 96, 2050, 128)])
+def test_proj_nll(ops, N, H, V, chunk):
+    h, W, b = rnd(N, H, seed=1), rnd(V, H, seed=2, scale=0.3), rnd(V, seed=3, scale=0.1)
+    labels = torch.randint(1, V, (N,), generator=torch.Generator().manual_seed(4))
+    labels[::7] = 0                                       # PAD rows are ignored
+    cnt = float((labels != 0).sum())
+    hc, Wc, bc = (t.clone().requires_grad_(True) for t in (h, W, b))
+    logp = torch.log_softmax(hc @ Wc.t() + bc, dim=1)
+    loss_c = torch.nn.functional.nll_loss(logp, labels, ignore_index=0)
+    (loss_c * 1.3).backward()
+    tok_c = -logp.detach().gather(1, labels.view(-1, 1)).view(-1) * (labels != 0)
+    hg, Wg, bg = (dev(t).requires_grad_(True) for t in (h, W, b))
+    row_scale = dev(torch.full((N,), 1.0 / cnt))
+    if chunk is not None:
+        tok, lse, dh, dW, db = ops.proj_nll_raw(hg.detach(), Wg.detach(), bg.detach(), dev(labels), row_scale, 0, True, chunk)
+        assert rel_err(tok.cpu(), tok_c) < 1e-5
+        assert rel_err(dh.cpu() * 1.3, hc.grad) < 1e-5 and rel_err(dW.cpu() * 1.3, Wc.grad) < 1e-5
+        assert rel_err(db.cpu() * 1.3, bc.grad) < 1e-5
+        assert rel_err(lse.cpu()[labels != 0], torch.logsumexp(h @ W.t() + b, dim=1)[labels != 0]) < 1e-5
+    loss_g, tok_g = ops.ProjNLLFunction.apply(hg, Wg, bg, dev(labels), row_scale, 0)
+    assert abs(float(loss_g) - float(loss_c)) < 1e-5 * abs(float(loss_c))
+    assert rel_err(tok_g.cpu(), tok_c) < 1e-5
+    (loss_g * 1.3).backward()
+    assert rel_err(hg.grad.cpu(), hc.grad) < 1e-5
+    assert rel_err(Wg.grad.cpu(), Wc.grad) < 1e-5
+    assert rel_err(bg.grad.cpu(), bc.grad) < 1e-5
+    # forward-only path (validation): same token NLLs, no gradient buffers
+    tok2, _, dh2, _, _ = ops.proj_nll_raw(dev(h), dev(W), dev(b), dev(labels), None, 0, False)
+    assert dh2 is None and rel_err(tok2.cpu(), tok_c) < 1e-5
+    red = ops.nll_reduce(tok2, dev(labels), 0).cpu()
+    assert abs(float(red[0]) - float(tok_c.sum())) < 1e-4 * abs(float(tok_c.sum())) and float(red[1]) == cnt
+
+
+def test_embed_gather_scatter(ops):
+    V, E, rows = 57, 24, 200
+    table = rnd(V, E, seed=1)
+    table[0] = 0
+    ids = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2))
+    keep = (torch.rand(rows, E, generator=torch.Generator().manual_seed(3)) >= 0.3)
+    w = rnd(rows, E, seed=4)
+    for use_keep in (False, True):
+        tc = table.clone().requires_grad_(True)
+        x = torch.nn.functional.embedding(ids, tc, padding_idx=0)
+        if use_keep:
+            x = x * (keep.float() / (1.0 - 0.3))
+        (x * w).sum().backward()
+        tg = dev(table).requires_grad_(True)
+        kd = dev(keep.to(torch.uint8)) if use_keep else None
+        xg = ops.EmbedFunction.apply(tg, dev(ids), kd, 0.3 if use_keep else 0.0, 0)
+        assert rel_err(xg.detach().cpu(), x.detach()) < 1e-6
+        (xg * dev(w)).sum().backward()
+        assert rel_err(tg.grad.cpu(), tc.grad) < 1e-5
+        assert float(tg.grad[0].abs().sum()) == 0.0
+    # E not a multiple of 4 -> scalar path
+    t2 = rnd(9, 6, seed=7)
+    i2 = torch.tensor([3, 0, 8, 8, 1])
+    assert torch.equal(ops.EmbedFunction.apply(dev(t2), dev(i2), None, 0.0, 0).cpu(), t2[i2])
+
+
+def test_rng_fills(ops):
+    u = ops.uniform(100000, 1234, 0, "cuda").cpu()
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+    # counter-based: a shard generated with an offset equals the slice of the full stream (GPU-count invariance)
+    u2 = ops.uniform(1000, 1234, 5000, "cuda").cpu()
+    assert torch.equal(u2, u[5000:6000])
+    keep = ops.dropout_keep_mask(200000, 0.3, 99, 0, "cuda").cpu().float()
+    assert abs(float(keep.mean()) - 0.7) < 0.01
+    assert torch.equal(ops.dropout_keep_mask(100, 0.3, 99, 777, "cuda").cpu().float(), keep[777:877])
+
+
+def test_adam(ops, O):
+    n = 10007
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.01)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pg, mg, vg = dev(p), dev(m), dev(v)
+    for step in range(1, 6):
+        gs = g * (1.0 + 0.1 * step)
+        O.adam_step(p, gs, m, v, step)
+        ops.adam_step(pg, dev(gs), mg, vg, step, 1e-3)
+    assert rel_err(pg.cpu(), p) < 1e-6 and rel_err(mg.cpu(), m) < 1e-6 and rel_err(vg.cpu(), v) < 1e-6
+
+
+def test_argmax_logsoftmax_greedy(ops, O):
+    N, V = 37, 1003
+    logits = rnd(N, V, seed=1, scale=4.0)
+    logits[5, 100] = logits[5, 900] = 9.0                 # tie -> lowest index
+    buf = dev(torch.zeros(N, ops.proj_ldl(V)))
+    buf[:, :V] = dev(logits)
+    from laed_amd._lib import check, lib, ptr, stream
+    ids = torch.empty(N, device="cuda", dtype=torch.int64)
+    check(lib.laed_argmax_rows(ptr(buf), N, V, buf.shape[1], ptr(ids, torch.int64), stream()), "argmax")
+    assert np.array_equal(ids.cpu().numpy(), logits.argmax(dim=1).numpy()) and int(ids[5]) == 100
+    ops.log_softmax_rows_(buf, V)
+    assert rel_err(buf[:, :V].cpu(), torch.log_softmax(logits, dim=1)) < 2e-6
+    # greedy decode loop vs the oracle
+    B, E, H, V2, L = 5, 12, 32, 41, 9
+    P = {"rnn.weight_ih_l0": rnd(3 * H, E, seed=2, scale=0.3), "rnn.weight_hh_l0": rnd(3 * H, H, seed=3, scale=0.3),
+         "rnn.bias_ih_l0": rnd(3 * H, seed=4, scale=0.3), "rnn.bias_hh_l0": rnd(3 * H, seed=5, scale=0.3),
+         "project.weight": rnd(V2, H, seed=6), "project.bias": rnd(V2, seed=7)}
+    emb, h0 = rnd(V2, E, seed=8), rnd(B, H, seed=9)
+    seq_c, _, logp_c = O.decoder_greedy(P, "", emb, h0, L, 2, 3)
+    ids_g, hbuf = ops.decode_greedy(dev(emb), dev(P["rnn.weight_ih_l0"]), dev(P["rnn.weight_hh_l0"]),
+                                    dev(P["rnn.bias_ih_l0"]), dev(P["rnn.bias_hh_l0"]), dev(P["project.weight"]),
+                                    dev(P["project.bias"]), dev(h0), L, 2)
+    top2 = logp_c.topk(2, dim=2)[0]
+    assert float((top2[..., 0] - top2[..., 1]).min()) > 1e-4   # fixture has no near-ties
+    assert np.array_equal(ids_g.t().cpu().numpy(), seq_c.numpy())
