@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void gumbel_latent_fwd_kernel(const float* __r
     const float s = grp_sum<W>(e);
     if (valid && log_qy != nullptr) log_qy[off] = (l - m) - logf(s);
 
+    if (u == nullptr) return;   // posterior only ("Hidden2Discrete"); block-uniform: no shuffles follow for anyone
     // y = softmax((logits + g)/tau), g = -log(-log(u+eps)+eps)  (nn_lib.py:232-242)
     float a = -INFINITY;
     if (valid) {
@@ -205,7 +206,7 @@ extern "C" int laed_gumbel_latent_fwd(const float* logits, const float* u, int64
     LAED_CHECK_ARG(R >= 0 && k > 0 && k <= 64, "gumbel_latent_fwd: need 0 < k <= 64 (got %d)", k);
     LAED_CHECK_ARG(tau > 0.f, "gumbel_latent_fwd: temperature must be positive");
     if (R == 0) return 0;
-    LAED_CHECK_ARG(logits && u && y, "gumbel_latent_fwd: null pointer");
+    LAED_CHECK_ARG(logits && ((u && y) || log_qy), "gumbel_latent_fwd: null pointer");
 #define CALL(W) hipLaunchKernelGGL((gumbel_latent_fwd_kernel<W>), dim3((unsigned)cdiv64(R, 256 / W)), dim3(256), 0, \
                                    (hipStream_t)stream, logits, u, R, k, tau, hard, y, ids, log_qy)
     DISPATCH_W(k, CALL);

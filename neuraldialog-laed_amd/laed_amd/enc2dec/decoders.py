@@ -1,0 +1,134 @@
+"""DecoderRNN with the reference's signature (laed/enc2dec/decoders.py:118-297), GRU / no-attention path.
+
+TEACH_FORCE returns a LazyLogProbs handle instead of the [B,T,V] log-prob tensor: NLLEntropy recognises it and
+runs projection + log-softmax + NLL (+ backward) fused; any other tensor-style use materialises the tensor, so the
+public contract still holds.  GEN/greedy runs the whole free-running loop in one C call (laed_gru_decode_greedy).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops, parallel
+from ..nn_lib import Embedding, Linear
+from .base_modules import BaseRNN
+
+TEACH_FORCE = "teacher_forcing"
+TEACH_GEN = "teacher_gen"
+GEN = "gen"
+
+
+class LazyLogProbs(object):
+    """log_softmax(project(h)) for h_tm [T,B,H] (time-major), not materialised until someone asks."""
+
+    def __init__(self, h_tm, project, batch_size):
+        self.h_tm = h_tm
+        self.project = project
+        self.B = batch_size
+        self.T = h_tm.shape[0]
+        self.V = project.weight.shape[0]
+        self.tok_nll = None
+        self._dense = None
+
+    def materialize(self):
+        """Dense [B,T,V] log-probs (detached; gradients flow only through the fused NLL path)."""
+        if self._dense is None:
+            with torch.no_grad():
+                h_bf = self.h_tm.detach().transpose(0, 1).reshape(self.B * self.T, -1)
+                buf = ops.logits_rows(h_bf, self.project.weight.detach(), self.project.bias.detach())
+                ops.log_softmax_rows_(buf, self.V)
+                self._dense = buf[:, :self.V].view(self.B, self.T, self.V)
+        return self._dense
+
+    def size(self, *a):
+        return torch.Size((self.B, self.T, self.V)) if not a else (self.B, self.T, self.V)[a[0]]
+
+    @property
+    def shape(self):
+        return self.size()
+
+    def __getattr__(self, name):            # .view / .exp / .topk / ... -> dense tensor semantics
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+
+class DecoderRNN(BaseRNN):
+    def __init__(self, vocab_size, max_len, input_size, hidden_size, sos_id, eos_id, n_layers=1, rnn_cell='lstm',
+                 input_dropout_p=0, dropout_p=0, use_attention=False, attn_mode='cat', attn_size=None, use_gpu=True,
+                 embedding=None, output_size=None, tie_output_embed=False):
+        super(DecoderRNN, self).__init__(vocab_size, input_size, hidden_size, input_dropout_p, dropout_p, n_layers,
+                                         rnn_cell, False)
+        if use_attention:
+            raise NotImplementedError("decoder attention is off in every LAED script (use_attn=False) and not built")
+        if tie_output_embed:
+            raise NotImplementedError("tie_output_embed is never enabled by the reference's models")
+        self.output_size = vocab_size if output_size is None else output_size
+        self.max_length = max_len
+        self.use_attention = use_attention
+        self.eos_id = eos_id
+        self.sos_id = sos_id
+        self.init_input = None
+        self.use_gpu = use_gpu
+        self.embedding = Embedding(vocab_size, self.input_size) if embedding is None else embedding
+        self.project = Linear(self.hidden_size, self.output_size)
+        # noise control for the fused input dropout (decoders.py:156)
+        self.drop_seed = 4321
+        self.drop_step = 0
+        self.injected_keep = None          # tests: keep mask [B,T,E] (1 keep / 0 drop), used instead of the RNG
+
+    def _keep_mask_tm(self, B, T, device):
+        """uint8 keep mask in time-major layout [T,B,E]; RNG keyed by the GLOBAL batch row."""
+        E = self.input_size
+        if self.injected_keep is not None:
+            keep = torch.as_tensor(self.injected_keep).to(device=device)
+            return (keep != 0).to(torch.uint8).view(B, T, E).transpose(0, 1).contiguous()
+        row0 = parallel.rank() * B
+        keep = ops.dropout_keep_mask(B * T * E, self.input_dropout_p,
+                                     (self.drop_seed * 1000003 + 2 * self.drop_step + 1) & 0xFFFFFFFFFFFFFFFF,
+                                     row0 * T * E, device)
+        self.drop_step += 1
+        return keep.view(B, T, E).transpose(0, 1).contiguous()
+
+    def forward_step(self, input_var, hidden, encoder_outputs=None):
+        """[B,T] ids, hidden [1,B,H] -> (lazy log-probs over [B,T,V], hidden [1,B,H], None)."""
+        B, T = input_var.size(0), input_var.size(1)
+        keep, p = None, 0.0
+        if self.training and self.input_dropout_p > 0:
+            keep, p = self._keep_mask_tm(B, T, input_var.device), self.input_dropout_p
+        embedded = self.embedding(input_var, keep=keep, drop_p=p)       # gather + dropout fused
+        out_tm, hT = self.rnn.forward_tm(embedded.transpose(0, 1), None if hidden is None else hidden[0])
+        return LazyLogProbs(out_tm, self.project, B), hT.unsqueeze(0), None
+
+    def forward(self, batch_size, inputs=None, init_state=None, attn_context=None, mode=TEACH_FORCE,
+                gen_type='greedy', beam_size=4):
+        ret_dict = dict()
+        if mode == GEN:
+            inputs = None
+        if mode == TEACH_FORCE:
+            if inputs is None:
+                raise ValueError("teacher forcing needs decoder inputs")
+            decoder_outputs, decoder_hidden, _ = self.forward_step(inputs, init_state, attn_context)
+            ret_dict[DecoderRNN.KEY_SEQUENCE] = []
+            ret_dict[DecoderRNN.KEY_LENGTH] = [self.max_length] * batch_size
+            return decoder_outputs, decoder_hidden, ret_dict
+        if gen_type != 'greedy':
+            raise NotImplementedError("gen_type '%s': only greedy decoding is on the hot path (sample/beam are "
+                                      "listed as next in SURVEY.md section 8f)" % gen_type)
+        with torch.no_grad():
+            h0 = init_state[0].detach().contiguous()
+            ids, hbuf = ops.decode_greedy(self.embedding.weight.detach(), self.rnn.weight_ih_l0.detach(),
+                                          self.rnn.weight_hh_l0.detach(), self.rnn.bias_ih_l0.detach(),
+                                          self.rnn.bias_hh_l0.detach(), self.project.weight.detach(),
+                                          self.project.bias.detach(), h0, self.max_length, self.sos_id)
+        # ids [L,B]; EOS bookkeeping as decoders.py:241-245 (first EOS position + 1, else max_length)
+        ids_bf = ids.t().contiguous()
+        host = ids_bf.cpu().numpy()
+        lengths = np.array([self.max_length] * batch_size)
+        for b in range(batch_size):
+            hit = np.nonzero(host[b] == self.eos_id)[0]
+            if hit.size:
+                lengths[b] = hit[0] + 1
+        ret_dict[DecoderRNN.KEY_SEQUENCE] = [ids_bf[:, t:t + 1] for t in range(self.max_length)]
+        ret_dict[DecoderRNN.KEY_LENGTH] = lengths.tolist()
+        decoder_outputs = LazyLogProbs(hbuf[1:], self.project, batch_size)
+        return decoder_outputs, hbuf[self.max_length].unsqueeze(0), ret_dict

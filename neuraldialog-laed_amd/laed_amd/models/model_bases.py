@@ -1,0 +1,51 @@
+"""BaseModel: np2var, backward, valid_loss, model_sel_loss, get_optimizer (mirror of
+laed/models/model_bases.py:45-133; the Adam branch runs the fused HIP Adam kernel)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import optim, parallel
+from ..utils import cast_type
+
+
+class BaseModel(nn.Module):
+    def __init__(self, config):
+        super(BaseModel, self).__init__()
+        self.use_gpu = config.use_gpu
+        self.flush_valid = False
+        self.config = config
+        self.kl_w = 0.0
+
+    def np2var(self, inputs, dtype):
+        """numpy (or tensor) -> device tensor of the requested tag (model_bases.py:53-57)."""
+        if inputs is None:
+            return None
+        if not torch.is_tensor(inputs):
+            inputs = torch.from_numpy(np.ascontiguousarray(inputs))
+        return cast_type(inputs, dtype, self.use_gpu)
+
+    def forward(self, *input):
+        raise NotImplementedError
+
+    def backward(self, batch_cnt, loss):
+        total_loss = self.valid_loss(loss, batch_cnt)
+        total_loss.backward()
+
+    def valid_loss(self, loss, batch_cnt=None):
+        total_loss = 0.0
+        for key, l in loss.items():
+            if l is not None:
+                total_loss += l
+        return total_loss
+
+    def model_sel_loss(self, loss, batch_cnt):
+        return self.valid_loss(loss, batch_cnt)
+
+    def get_optimizer(self, config):
+        """model_bases.py:121-133.  Adam (the scripts' default, op='adam') = fused HIP kernel; under data
+        parallelism the optimizer first joins the overlapped gradient all-reduce."""
+        if config.op != 'adam':
+            raise NotImplementedError("optimizer '%s': only op='adam' (the default of every script) is built" % config.op)
+        params = [p for p in self.parameters() if p.requires_grad]
+        reducer = parallel.GradReducer(params) if parallel.group() is not None else None
+        return optim.FusedAdam(params, lr=config.init_lr, reducer=reducer)

@@ -1,0 +1,166 @@
+"""DI-VAE and DI-VST (mirror of laed/models/sent_models.py:20-165, 278-442) on the HIP engine.
+
+Same constructor arguments, config attributes, state_dict keys, forward/valid_loss/backward semantics and
+returned Pack keys as the reference; analysis-only helpers (sweep / enumerate / exp_enumerate) are out of scope.
+One deliberate difference, documented in DESIGN.md: valid_loss sums out of place, so loss.nll read after
+backward() is still the clean NLL (the reference aliases and mutates it, sent_models.py:88-90).
+"""
+import torch
+import torch.nn as nn
+
+from .. import criterions, nn_lib
+from ..enc2dec.base_modules import BOS, EOS, PAD
+from ..enc2dec.decoders import GEN, DecoderRNN
+from ..enc2dec.encoders import EncoderRNN
+from ..utils import LONG, Pack
+from .model_bases import BaseModel
+
+
+class _SentBase(BaseModel):
+    """Shared constructor part of DiVAE / DiVST (sent_models.py:21-58, 279-316)."""
+
+    def _build_common(self, corpus, config, connector_bias):
+        self.vocab = corpus.vocab
+        self.rev_vocab = corpus.rev_vocab
+        self.vocab_size = len(self.vocab)
+        self.embed_size = config.embed_size
+        self.max_utt_len = config.max_utt_len
+        self.go_id = self.rev_vocab[BOS]
+        self.eos_id = self.rev_vocab[EOS]
+        self.num_layer = config.num_layer
+        self.dropout = config.dropout
+        self.enc_cell_size = config.enc_cell_size
+        self.dec_cell_size = config.dec_cell_size
+        self.rnn_cell = config.rnn_cell
+        self.max_dec_len = config.max_dec_len
+        self.use_attn = config.use_attn
+        self.beam_size = config.beam_size
+        self.utt_type = config.utt_type
+        self.bi_enc_cell = config.bi_enc_cell
+        self.attn_type = config.attn_type
+        self.enc_out_size = self.enc_cell_size * 2 if self.bi_enc_cell else self.enc_cell_size
+
+        self.embedding = nn_lib.Embedding(self.vocab_size, self.embed_size, padding_idx=self.rev_vocab[PAD])
+        self.x_encoder = EncoderRNN(self.embed_size, self.enc_cell_size, dropout_p=self.dropout,
+                                    rnn_cell=self.rnn_cell, variable_lengths=getattr(config, 'fix_batch', False),
+                                    bidirection=self.bi_enc_cell)
+        self.q_y = nn_lib.Linear(self.enc_out_size, config.y_size * config.k)
+        self.cat_connector = nn_lib.GumbelConnector()
+        self.dec_init_connector = nn_lib.LinearConnector(config.y_size * config.k, self.dec_cell_size,
+                                                         self.rnn_cell == 'lstm', has_bias=connector_bias)
+
+    def _make_decoder(self):
+        return DecoderRNN(self.vocab_size, self.max_dec_len, self.embed_size, self.dec_cell_size, self.go_id,
+                          self.eos_id, n_layers=1, rnn_cell=self.rnn_cell, input_dropout_p=self.dropout,
+                          dropout_p=self.dropout, use_attention=self.use_attn, attn_size=self.enc_cell_size,
+                          attn_mode=self.attn_type, use_gpu=self.use_gpu, embedding=self.embedding)
+
+    def _build_losses(self, config):
+        self.nll_loss = criterions.NLLEntropy(self.rev_vocab[PAD], self.config)
+        self.cat_kl_loss = criterions.CatKLLoss()
+        self.entropy_loss = criterions.Entropy()
+        self.bpr_loss = criterions.BatchPriorKL(config.y_size, config.k, config.use_mutual)
+
+    def _encode_latent(self, out_utts, temperature):
+        """utterance -> (log_qy [B*y,k], y_ids [B,y], dec_init_state [1,B,H])   (sent_models.py:99-119)."""
+        output_embedding = self.embedding(out_utts)
+        x_outs, x_last = self.x_encoder(output_embedding)
+        x_last = x_last.transpose(0, 1).contiguous().view(-1, self.enc_out_size)
+        qy_logits = self.q_y(x_last).view(-1, self.config.k)
+        # one kernel: posterior log-softmax + Gumbel-softmax sample (+ argmax ids); noise is drawn in eval too
+        sample_y, y_ids, log_qy = self.cat_connector(qy_logits, temperature, self.use_gpu, hard=not self.training,
+                                                     return_max_id=True, return_log_qy=True)
+        sample_y = sample_y.view(-1, self.config.k * self.config.y_size)
+        y_ids = y_ids.view(-1, self.config.y_size)
+        dec_init_state = self.dec_init_connector(sample_y)
+        return log_qy, y_ids, dec_init_state
+
+
+class DiVAE(_SentBase):
+    def __init__(self, corpus, config):
+        super(DiVAE, self).__init__(config)
+        if getattr(config, 'train_prior', False):
+            raise NotImplementedError("train_prior=True is off in ptb-utt.py's defaults and not built")
+        self._build_common(corpus, config, connector_bias=False)
+        self.decoder = self._make_decoder()
+        self._build_losses(config)
+        self.log_py = nn.Parameter(torch.log(torch.ones(self.config.y_size, self.config.k) / config.k),
+                                   requires_grad=True)
+        self.kl_w = 0.0
+
+    def valid_loss(self, loss, batch_cnt=None):
+        total_loss = loss.nll
+        if self.config.use_reg_kl:
+            total_loss = total_loss + loss.reg_kl
+        return total_loss
+
+    def forward(self, data_feed, mode, gen_type='greedy', sample_n=1, return_latent=False):
+        batch_size = len(data_feed['output_lens'])
+        out_utts = self.np2var(data_feed['outputs'], LONG)
+        log_qy, y_ids, dec_init_state = self._encode_latent(out_utts, 1.0)
+
+        labels = out_utts[:, 1:].contiguous()
+        dec_inputs = out_utts[:, 0:-1]
+        dec_outs, dec_last, dec_ctx = self.decoder(batch_size, dec_inputs, dec_init_state, mode=mode,
+                                                   gen_type=gen_type, beam_size=self.beam_size)
+        if mode == GEN:
+            return dec_ctx, labels
+        nll = self.nll_loss(dec_outs, labels)
+        self._last_dec_outs = dec_outs
+        reg_kl, b_pr, mi = self.bpr_loss(log_qy)
+        results = Pack(nll=nll, reg_kl=reg_kl, mi=mi, bpr=b_pr)
+        if return_latent:
+            results['log_qy'] = log_qy
+            results['dec_init_state'] = dec_init_state
+            results['y_ids'] = y_ids
+        return results
+
+
+    def nll_loss_tok(self):
+        """Per-token NLL [B,T-1] of the last teacher-forced forward (0 at PAD targets), as a host array."""
+        return self._last_dec_outs.tok_nll.detach().cpu().numpy()
+
+
+class DiVST(_SentBase):
+    def __init__(self, corpus, config):
+        super(DiVST, self).__init__(config)
+        self._build_common(corpus, config, connector_bias=True)
+        self.prev_decoder = self._make_decoder()
+        self.next_decoder = self._make_decoder()
+        self._build_losses(config)
+        self.kl_w = 1.0
+
+    def backward(self, batch_cnt, loss):
+        total_loss = self.valid_loss(loss)
+        total_loss.backward()
+
+    def valid_loss(self, loss, batch_cnt=None):
+        total_loss = loss.prev_nll + loss.next_nll
+        if self.config.use_reg_kl:
+            total_loss = total_loss + loss.reg_kl
+        return total_loss
+
+    def forward(self, data_feed, mode, gen_type='greedy', sample_n=1, return_latent=False):
+        batch_size = len(data_feed['output_lens'])
+        out_utts = self.np2var(data_feed['outputs'], LONG)
+        prev_utts = self.np2var(data_feed['prevs'], LONG)
+        next_utts = self.np2var(data_feed['nexts'], LONG)
+        log_qy, y_ids, dec_init_state = self._encode_latent(out_utts, self.kl_w)
+
+        prev_labels = prev_utts[:, 1:].contiguous()
+        next_labels = next_utts[:, 1:].contiguous()
+        prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
+                                                           gen_type=gen_type, beam_size=self.beam_size)
+        next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state, mode=mode,
+                                                           gen_type=gen_type, beam_size=self.beam_size)
+        if mode == GEN:
+            return (prev_dec_ctx, next_dec_ctx), (prev_labels, next_labels)
+        prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
+        next_nll = self.nll_loss(next_dec_outs, next_labels)
+        reg_kl, b_pr, mi = self.bpr_loss(log_qy)
+        results = Pack(prev_nll=prev_nll, next_nll=next_nll, reg_kl=reg_kl, mi=mi, b_pr=b_pr)
+        if return_latent:
+            results['log_qy'] = log_qy
+            results['dec_init_state'] = dec_init_state
+            results['y_ids'] = y_ids
+        return results

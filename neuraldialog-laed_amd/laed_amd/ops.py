@@ -342,3 +342,26 @@ class ProjNLLFunction(torch.autograd.Function):
         for t in (dh, dW, db):
             check(lib.laed_scale_by_dev(ptr(t), ptr(t), ptr(g), t.numel(), stream()), "laed_scale_by_dev")
         return dh, dW, db, None, None, None
+
+
+class LogSoftmaxKFunction(torch.autograd.Function):
+    """log_softmax over the last (k <= 64) dimension of a [R,k] matrix: the posterior log q(y|x)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        logits = _f32c(logits)
+        R, k = logits.shape
+        log_qy = torch.empty_like(logits)
+        check(lib.laed_gumbel_latent_fwd(ptr(logits), None, R, k, 1.0, 0, None, None, ptr(log_qy), stream()),
+              "laed_gumbel_latent_fwd")
+        ctx.save_for_backward(log_qy)
+        return log_qy
+
+    @staticmethod
+    def backward(ctx, dlq):
+        (log_qy,) = ctx.saved_tensors
+        R, k = log_qy.shape
+        dlogits = torch.empty_like(log_qy)
+        check(lib.laed_gumbel_latent_bwd(None, None, ptr(log_qy), ptr(_f32c(dlq)), R, k, 1.0, ptr(dlogits), stream()),
+              "laed_gumbel_latent_bwd")
+        return dlogits
