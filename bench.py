@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""DI-VAE train-step benchmark on MI355X (BASELINE.json: train tokens/s, whole node; fwd+bwd step ms).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload "S-fixed" (BASELINE.json configs[4]): DI-VAE, V=50000, E=200, H_enc=H_dec=1024, y=20, k=10,
+T=40, GLOBAL batch 4096 (strong scaling: 4096/N sequences per GPU), every row [<s>, Zipf ids..., </s>], fp32,
+dropout 0.3 on, Gumbel noise + dropout from the library's counter RNG keyed by global row.  A step =
+zero_grad + forward(TEACH_FORCE) + backward (+ overlapped RCCL gradient all-reduce) + fused Adam
+(laed/main.py:104-113 order).  Token = non-PAD decoder target position (the 'word' NLL denominator).
+
+One JSON line on rank 0.  `roofline` is measured live: HIP events bracket every GEMM launch of the timed steps on
+their own stream (laed_prof_*); the dominant GEMM variant's algorithmic FLOP / its summed duration is `achieved`.
+`cpu_baseline` (rank 0, N=1 only) times the oracle's nn.Module restatement (the reference's PyTorch CPU path) on a
+bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "neuraldialog-laed_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+VARIANTS = ["sgemm_128x128_NT", "sgemm_64x64_NT", "sgemm_128x128_NN", "sgemm_64x64_NN", "sgemm_128x128_TN",
+            "sgemm_64x64_TN"]
+
+SHAPES = {
+    # name: (V, E, H, y, k, T, global batch)
+    "S-fixed": (50000, 200, 1024, 20, 10, 40, 4096),      # BASELINE.json configs[4] (headline)
+    "P-fixed": (10002, 200, 512, 20, 10, 40, 30),         # ptb-utt.py defaults (configs[0] shape)
+}
+
+
+class Corpus(object):
+    def __init__(self, V):
+        self.vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
+        self.rev_vocab = {w: i for i, w in enumerate(self.vocab)}
+
+
+def make_config(E, H, y, k, T, batch, use_gpu=True):
+    return Namespace(embed_size=E, max_utt_len=T, num_layer=1, dropout=0.3, enc_cell_size=H, dec_cell_size=H,
+                     rnn_cell='gru', max_dec_len=T, use_attn=False, beam_size=10, utt_type='rnn', bi_enc_cell=False,
+                     attn_type='cat', fix_batch=False, y_size=y, k=k, use_gpu=use_gpu, avg_type='word',
+                     use_mutual=True, use_reg_kl=True, train_prior=False, init_lr=0.001, op='adam', batch_size=batch)
+
+
+def synth_batch(V, T, B, seed=1234):
+    """[B,T] int32: <s>=2, Zipf(s=1) interior ids over [4,V), </s>=3 (SURVEY.md 8d 'S-fixed')."""
+    rs = np.random.RandomState(seed)
+    ranks = np.arange(1, V - 4 + 1, dtype=np.float64)
+    p = 1.0 / ranks
+    p /= p.sum()
+    out = np.empty((B, T), dtype=np.int32)
+    out[:, 0] = 2
+    out[:, 1:T - 1] = 4 + rs.choice(V - 4, size=(B, T - 2), p=p)
+    out[:, T - 1] = 3
+    return out
+
+
+def flops_per_step(V, E, H, y, k, T, B):
+    f_enc = 2.0 * 3 * H * (E + H)
+    f_dec = 2.0 * 3 * H * (E + H) + 2.0 * H * V
+    f_seq = 2.0 * H * y * k + 2.0 * y * k * H
+    return 3.0 * (B * T * f_enc + B * (T - 1) * f_dec + B * f_seq)
+
+
+def cpu_baseline(V, E, H, y, k, T, sample_b, steps=2):
+    """Oracle nn.Module DiVAE (== the reference's stock-torch CPU path) on `sample_b` sequences of the workload."""
+    from oracle.laed_oracle import OracleDiVAE
+    torch.manual_seed(0)
+    cfg = make_config(E, H, y, k, T, sample_b, use_gpu=False)
+    model = OracleDiVAE(V, cfg)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.init_lr)
+    batch = synth_batch(V, T, sample_b)
+    rs = np.random.RandomState(7)
+
+    def step():
+        u = rs.uniform(size=(sample_b * y, k)).astype(np.float32)
+        opt.zero_grad()
+        res = model(batch, u)
+        res["total"].backward()
+        opt.step()
+    step()                                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return sample_b * (T - 1) / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="S-fixed", choices=sorted(SHAPES))
+    ap.add_argument("--global-batch", type=int, default=0, help="override the workload's global batch")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+
+    import torch.distributed as dist
+    from laed_amd import parallel
+    from laed_amd._lib import lib
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from laed_amd.models.sent_models import DiVAE
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        parallel.init()
+
+    V, E, H, y, k, T, GB = SHAPES[args.workload]
+    if args.global_batch:
+        GB = args.global_batch
+    if GB % world:
+        raise SystemExit("global batch %d not divisible by %d GPUs" % (GB, world))
+    per = GB // world
+
+    torch.manual_seed(0)                                     # identical replicas on every rank
+    cfg = make_config(E, H, y, k, T, GB)
+    model = DiVAE(Corpus(V), cfg).cuda()
+    model.train()
+    opt = model.get_optimizer(cfg)
+    full = synth_batch(V, T, GB)
+    shard = torch.from_numpy(full[rank * per:(rank + 1) * per].astype(np.int64)).cuda()   # inputs resident in HBM
+    feed = {"outputs": shard, "output_lens": [T] * per}
+    tokens_per_step = GB * (T - 1)
+
+    def step():
+        opt.zero_grad()
+        loss = model(feed, mode=TEACH_FORCE)
+        model.backward(0, loss)
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof = not args.no_prof
+    if prof:
+        lib.laed_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof_out = (ctypes.c_double * 18)()
+    if prof:
+        lib.laed_prof_enable(0)
+        lib.laed_prof_collect(prof_out)
+    nll = float(loss.nll)
+    if world > 1:
+        t = torch.tensor([elapsed, nll], device="cuda", dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)           # per-rank NLL shares sum to the global NLL
+        elapsed, nll = float(tmax[0]), float(t[1])
+
+    # fwd+bwd (no Adam) step time, measured separately after the timed region
+    fence()
+    t1 = time.perf_counter()
+    nfb = max(2, args.steps // 2)
+    for _ in range(nfb):
+        opt.zero_grad()
+        model.backward(0, model(feed, mode=TEACH_FORCE))
+        if opt.reducer is not None:
+            opt.reducer.wait()
+    fence()
+    fwd_bwd_ms = (time.perf_counter() - t1) / nfb * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = tokens_per_step * args.steps / elapsed
+        roofline = None
+        if prof:
+            rows = [(prof_out[v * 3 + 1], v) for v in range(6) if prof_out[v * 3] > 0]
+            tot_ms = sum(r[0] for r in rows)
+            ms, v = max(rows)
+            cnt, flops = prof_out[v * 3], prof_out[v * 3 + 2]
+            achieved = flops / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": VARIANTS[v], "achieved": round(achieved, 2),
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "traffic": None, "launches": int(cnt), "avg_launch_ms": round(ms / cnt, 4),
+                        "gemm_share_of_step": round(tot_ms / args.steps / ms_per_step, 4),
+                        "all_gemm_tflops": round(sum(prof_out[i * 3 + 2] for i in range(6)) / (tot_ms * 1e-3) / 1e12, 2)}
+        out = {
+            "metric": "train tokens/sec (DI-VAE, whole node)", "value": round(value, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "fwd_bwd_ms": round(fwd_bwd_ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "vocab": V, "embed": E, "hidden": H, "y_size": y, "k": k,
+                       "seq_len": T, "global_batch": GB, "per_gpu_batch": per, "parallelism": "dp%d" % world,
+                       "tokens_per_step": tokens_per_step},
+            "step_tflops": round(flops_per_step(V, E, H, y, k, T, GB) / (ms_per_step * 1e-3) / 1e12, 2),
+            "final_nll": round(nll, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or torch.get_num_threads())
+            tps, dt = cpu_baseline(V, E, H, y, k, T, args.cpu_sample)
+            out["cpu_baseline"] = {"value": round(tps, 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "ms_per_step": round(dt * 1e3, 1),
+                                   "sample": "%s shape, %d sequences/step (same step order), 1 warm-up + 2 timed steps"
+                                             % (args.workload, args.cpu_sample)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,15 @@ int laed_dot(const float* a, const float* b, int64_t n, float* out, void* stream
 int laed_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream);   /* y = a*x + b*y */
 int laed_scale_by_dev(float* y, const float* x, const float* s, int64_t n, void* stream); /* y = s[0]*x */
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (no counterpart in the reference): when enabled, every GEMM launch is bracketed by HIP events
+ * on its own stream.  laed_prof_collect waits for them and fills a HOST array of 18 doubles:
+ * out[v*3+0..2] = {launches, total ms, total algorithmic flops} for variant v = layout*2 + tile,
+ * layout 0 = NT (x W^T), 1 = NN (dy W), 2 = TN (dy^T x); tile 0 = 128x128, 1 = 64x64.
+ * ------------------------------------------------------------------------------------------ */
+int laed_prof_enable(int on);
+int laed_prof_collect(double* out_host18);
+
 #ifdef __cplusplus
 }
 #endif

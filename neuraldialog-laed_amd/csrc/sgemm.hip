@@ -14,7 +14,25 @@
 // so the blocks resident on one XCD at a time share A row panels and walk the same B column panels.
 #include "laed_common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace {
+
+// ---- optional live profiler (bench.py's roofline leg): HIP events around every GEMM launch, on the launch stream.
+// Off by default; when off the launch path touches none of this.  Variant id = layout*2 + (big tile ? 0 : 1).
+struct ProfRec { hipEvent_t start, stop; double flops; int variant; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
 
 struct SgemmArgs {
     const float* A;
@@ -244,7 +262,20 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     p.tiles_n = (a.N + BN - 1) / BN;
     int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, p);
+    if (g_prof_on) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        ProfRec r;
+        r.start = prof_event();
+        r.stop = prof_event();
+        r.flops = 2.0 * a.M * a.N * a.K;
+        r.variant = (TA ? 2 : (TB ? 0 : 1)) * 2 + (BM == 128 ? 0 : 1);
+        (void)hipEventRecord(r.start, stream);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, p);
+        (void)hipEventRecord(r.stop, stream);
+        g_prof_recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, p);
+    }
     LAED_LAUNCH_CHECK("sgemm");
     return 0;
 }
@@ -288,4 +319,31 @@ extern "C" int laed_sgemm(int transA, int transB, int M, int N, int K,
                           float* colsum_a, int colsum_accumulate, void* stream) {
     return laed_sgemm_impl(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate != 0,
                            colsum_a, colsum_accumulate != 0, (hipStream_t)stream);
+}
+
+// ---- profiler C ABI (measurement aid; not part of the compute path)
+extern "C" int laed_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// Waits for every recorded launch, then fills out[variant*3 + {0,1,2}] = {launches, total ms, total flops} for the
+// 6 GEMM variants (NT, NN, TN) x (128x128, 64x64) and clears the records.  `out` is a HOST array of 18 doubles.
+extern "C" int laed_prof_collect(double* out) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < 18; ++i) out[i] = 0.0;
+    for (auto& r : g_prof_recs) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.stop);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.start, r.stop);
+        if (e != hipSuccess) return laed_fail((int)e, "prof_collect: %s", hipGetErrorString(e));
+        out[r.variant * 3 + 0] += 1.0;
+        out[r.variant * 3 + 1] += ms;
+        out[r.variant * 3 + 2] += r.flops;
+        g_prof_pool.push_back(r.start);
+        g_prof_pool.push_back(r.stop);
+    }
+    g_prof_recs.clear();
+    return 0;
 }
