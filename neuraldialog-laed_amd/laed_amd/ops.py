@@ -86,12 +86,18 @@ def workspace(key, numel, device):
     return t
 
 
-def proj_chunk_rows(N, V):
-    """Rows per logits chunk: ~1 GiB of workspace at most, at least 1024 rows."""
+def proj_chunk_rows(N, V, H=1024):
+    """Rows per logits chunk.  The dh GEMM of a chunk has (rows/128) x (H/128) block tiles and the chip runs
+    2 blocks on each of its 256 CUs, so rows are chosen to make that a multiple of 512 tiles (8192 rows at
+    H=1024) within ~2 GiB of workspace; small problems use one chunk."""
     ldl = proj_ldl(V)
-    rows = max(1024, (1 << 28) // ldl)
-    rows = (rows // 128) * 128
-    return int(min(max(N, 1), rows))
+    cap = max(1024, (1 << 29) // ldl)                       # rows that fit 2 GiB of fp32 workspace
+    if N <= cap:
+        return int(max(N, 1))
+    tiles_n = max(1, (H + 127) // 128)
+    unit = max(128, (512 // tiles_n) * 128) if tiles_n <= 512 else 128
+    rows = (cap // unit) * unit if cap >= unit else (cap // 128) * 128
+    return int(max(rows, 128))
 
 
 def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None):
@@ -99,7 +105,7 @@ def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None)
     V = W.shape[0]
     dev = h.device
     if chunk_rows is None:
-        chunk_rows = proj_chunk_rows(N, V)
+        chunk_rows = proj_chunk_rows(N, V, H)
     ws = workspace("proj", chunk_rows * proj_ldl(V), dev)
     tok = torch.empty(N, device=dev, dtype=torch.float32)
     lse = torch.empty(N, device=dev, dtype=torch.float32)
