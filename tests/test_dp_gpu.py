@@ -1,0 +1,83 @@
+"""Data-parallel train step with the real HIP kernels: 2 ranks (both on cuda:0 of the 1-GPU box, gloo transport so
+the test does not need two devices) must reproduce the reference's single-process global-batch loss terms and
+gradients.  On the 8-GPU node the same code path runs with backend "nccl" (RCCL over xGMI), one rank per GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, result_dir):
+    for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from helpers import golden_config, load_golden, rel_err
+    from laed_amd import parallel
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from laed_amd.models.sent_models import DiVAE
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    parallel.init()
+    G = load_golden("divae_mid")
+    cfg = golden_config(G)
+    cfg.use_gpu = True
+
+    class Corpus(object):
+        vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, int(G["config/vocab_size"]))]
+        rev_vocab = {w: i for i, w in enumerate(vocab)}
+
+    model = DiVAE(Corpus(), cfg)
+    model.load_state_dict({k: torch.from_numpy(np.array(G["sd/" + k])) for k in model.state_dict()})
+    model.cuda().train()
+    B = G["in/outputs"].shape[0]
+    b0, b1 = parallel.shard_rows(B)
+    y = int(cfg.y_size)
+    ud = torch.from_numpy(G["in/u_steps"][0][b0 * y:b1 * y]).cuda()
+    model.cat_connector.sample_uniform = lambda logits: ud
+    opt = model.get_optimizer(cfg)
+    assert opt.reducer is not None and opt.reducer.enabled
+    opt.zero_grad()
+    loss = model({"outputs": G["in/outputs"][b0:b1], "output_lens": [0] * (b1 - b0)}, mode=TEACH_FORCE)
+    model.backward(0, loss)
+    opt.reducer.wait()
+    torch.cuda.synchronize()
+    nll = loss.nll.detach().reshape(1).clone()
+    dist.all_reduce(nll)                                   # per-rank shares of the global 'word' NLL
+    assert abs(float(nll) - float(G["out/nll"])) < 1e-4 * abs(float(G["out/nll"]))
+    for k in ("reg_kl", "bpr"):                            # global-batch statistics: identical on every rank
+        assert abs(float(loss[k]) - float(G["out/" + k])) < 1e-7 + 1e-4 * abs(float(G["out/" + k])), k
+    for n, p in model.named_parameters():
+        g = G["grad/" + n]
+        if g.size:
+            assert rel_err(p.grad.cpu(), g) < 2e-4, (n, rel_err(p.grad.cpu(), g))
+    opt.step()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        assert float((p.detach().cpu() - torch.from_numpy(G["p1/" + n])).abs().max()) < 1e-4, n
+    dist.destroy_process_group()
+    open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
+
+
+def test_two_rank_step_equals_reference_global_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(str(tmp_path))) == ["ok0", "ok1"]

@@ -1,0 +1,114 @@
+"""CPU-only tests of the host-side mirror of the reference API (no kernels are launched)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_config, load_golden
+
+
+class Corpus(object):
+    def __init__(self, V):
+        self.vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
+        self.rev_vocab = {w: i for i, w in enumerate(self.vocab)}
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    from laed_amd.models.sent_models import DiVAE, DiVST
+    for name, cls in (("divae_tiny", DiVAE), ("divst_tiny", DiVST)):
+        G = load_golden(name)
+        model = cls(Corpus(int(G["config/vocab_size"])), golden_config(G))
+        assert list(model.state_dict().keys()) == [str(k) for k in G["meta/state_dict_keys"]]
+        for k, v in model.state_dict().items():
+            assert tuple(v.shape) == G["sd/" + k].shape, k
+        # the decoder embedding is the shared table (sent_models.py:70) and PAD row is zero
+        dec = model.decoder if name == "divae_tiny" else model.prev_decoder
+        assert dec.embedding.weight is model.embedding.weight
+        assert float(model.embedding.weight[0].abs().sum()) == 0.0
+        model.load_state_dict({k: torch.from_numpy(np.array(G["sd/" + k])) for k in model.state_dict()})
+
+
+def test_same_seed_same_init_as_torch_modules():
+    """GRU / Linear / Embedding keep torch's initialisation order: same manual_seed -> same weights as nn.GRU etc."""
+    from laed_amd.enc2dec.base_modules import GRU
+    torch.manual_seed(3)
+    a = GRU(6, 10, bidirectional=True)
+    torch.manual_seed(3)
+    b = torch.nn.GRU(6, 10, 1, batch_first=True, bidirectional=True)
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa, pb)
+
+
+def test_unsupported_options_fail_loudly():
+    from laed_amd.enc2dec.decoders import DecoderRNN
+    from laed_amd.enc2dec.encoders import EncoderRNN
+    from laed_amd.nn_lib import LinearConnector
+    with pytest.raises(NotImplementedError):
+        EncoderRNN(4, 8, rnn_cell='lstm')
+    with pytest.raises(NotImplementedError):
+        EncoderRNN(4, 8, variable_lengths=True)
+    with pytest.raises(NotImplementedError):
+        DecoderRNN(10, 5, 4, 8, 2, 3, rnn_cell='gru', use_attention=True)
+    with pytest.raises(NotImplementedError):
+        LinearConnector(4, 8, True)
+    with pytest.raises(ValueError):
+        EncoderRNN(4, 8, rnn_cell='rnn')
+
+
+def test_forward_needs_the_gpu_no_cpu_fallback():
+    from laed_amd._lib import LaedError
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from laed_amd.models.sent_models import DiVAE
+    G = load_golden("divae_tiny")
+    cfg = golden_config(G)
+    model = DiVAE(Corpus(int(G["config/vocab_size"])), cfg)      # use_gpu False in the golden config
+    with pytest.raises(LaedError):
+        model({"outputs": G["in/outputs"], "output_lens": G["in/output_lens"].tolist()}, mode=TEACH_FORCE)
+
+
+def test_criterions_dense_path_vs_reference_goldens():
+    from argparse import Namespace
+    from laed_amd import criterions
+    G = load_golden("modules")
+    logp, labels = torch.from_numpy(G["nll/logp"]), torch.from_numpy(G["nll/labels"])
+    for avg in (None, "seq", "real_word", "word"):
+        crit = criterions.NLLEntropy(0, Namespace(avg_type=avg, use_gpu=False))
+        assert abs(float(crit(logp, labels)) - float(G["nll/out_%s" % avg])) < 1e-5, avg
+    with pytest.raises(ValueError):
+        criterions.NLLEntropy(0, Namespace(avg_type="bogus", use_gpu=False))(logp, labels)
+    lq, lp = torch.from_numpy(G["catkl/log_qy"]), torch.from_numpy(G["catkl/log_py"])
+    assert abs(float(criterions.CatKLLoss()(lq, lp, 4, unit_average=True)) - float(G["catkl/unit"])) < 1e-6
+    assert abs(float(criterions.CatKLLoss()(lq, lp, 4, unit_average=False)) - float(G["catkl/batch"])) < 1e-6
+    assert abs(float(criterions.Entropy()(lq, unit_average=True)) - float(G["entropy/unit"])) < 1e-6
+    assert abs(float(criterions.Entropy()(lq, 4, unit_average=False)) - float(G["entropy/batch"])) < 1e-6
+
+
+def test_pack_and_cast_type():
+    from laed_amd.utils import FLOAT, INT, LONG, Pack, cast_type, str2bool
+    p = Pack(a=1)
+    p.add(b=[1, 2])
+    q = p.copy()
+    q.b.append(3)
+    assert p.a == 1 and p.b == [1, 2] and q.b == [1, 2, 3]
+    with pytest.raises(AttributeError):
+        p.missing
+    t = torch.tensor([1.7, 2.2])
+    assert cast_type(t, LONG, False).dtype == torch.int64 and cast_type(t, INT, False).dtype == torch.int32
+    assert cast_type(t.long(), FLOAT, False).dtype == torch.float32
+    with pytest.raises(ValueError):
+        cast_type(t, 7, False)
+    assert str2bool("True") and str2bool("1") and not str2bool("no")
+
+
+def test_proj_chunk_rows_fill_whole_cu_waves():
+    from laed_amd.ops import proj_chunk_rows
+    assert proj_chunk_rows(159744, 50000, 1024) == 8192         # 64 x 8 = 512 block tiles = 2 per CU
+    assert proj_chunk_rows(1170, 10002, 512) == 1170            # small problem: one chunk
+    r = proj_chunk_rows(10 ** 6, 50000, 512)
+    assert r % 128 == 0 and r * 50016 * 4 <= (1 << 31)
+
+
+def test_greedy_connector():
+    from laed_amd.nn_lib import GreedyConnector
+    logits = torch.tensor([[0.1, 2.0, 2.0], [3.0, -1.0, 0.0]])
+    y, ids = GreedyConnector()(logits, False, return_max_id=True)
+    assert ids.view(-1).tolist() == [1, 0] and y.tolist() == [[0, 1, 0], [1, 0, 0]]
