@@ -154,36 +154,131 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     float4 ra[NLA], rb[NLB];
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
-
+    const int lrow = lane & 31, lk = lane >> 5;
     const int nkt = (p.K + BK - 1) / BK;
-    tile_load<AK, BM, VEC>(p.A, p.lda, m0, 0, p.M, p.K, tid, ra);
-    tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, 0, p.N, p.K, tid, rb);
-    if (TA && do_colsum) {
+    const float* a_base = sA + wm * (BM / 2) + lrow + lk * SA;   // fragment row (2*kk + lk) folded into the base
+    const float* b_base = sB + wn * (BN / 2) + lrow + lk * SB;
+
+    auto add_colsum = [&]() {
+        if (TA && do_colsum) {
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+            for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+        }
+    };
+
+    // Interior blocks with vector-loadable operands run their full K tiles on the scheduled loop: a straight-line
+    // body whose global loads (tile t+1), LDS fragment reads (next k pair) and LDS stores (tile t+1) are placed one
+    // by one in the issue gaps between consecutive MFMAs (a 32x32x2 f32 MFMA holds the matrix pipe for 64 cycles
+    // and a wave issues in order, so whatever sits between two MFMAs is hidden).  Edge blocks and the K tail use
+    // the generic loop with the guarded loader.
+    const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const int nfull = p.K / BK;          // K tiles that need no K-tail guard
+    const bool fast = interior && nfull > 0;
+    constexpr int NMF = TM * TN;         // MFMAs per k pair
+    constexpr int Q = (BK / 2) * NMF;    // MFMA issue gaps per K tile
+    constexpr int NL = NLA + NLB;
+
+    // per-thread source pointers of the first float4 of K tile 0; the NL loads per operand are a fixed stride apart
+    const float* ga;
+    const float* gb;
+    int64_t a_step, b_step, a_ist, b_ist;
+    if (AK) { ga = p.A + (int64_t)(m0 + tid / (BK / 4)) * p.lda + 4 * (tid % (BK / 4)); a_step = BK; a_ist = (int64_t)(NT / (BK / 4)) * p.lda; }
+    else    { ga = p.A + (int64_t)(tid / (BM / 4)) * p.lda + m0 + 4 * (tid % (BM / 4)); a_step = (int64_t)BK * p.lda; a_ist = (int64_t)(NT / (BM / 4)) * p.lda; }
+    if (BKC) { gb = p.B + (int64_t)(n0 + tid / (BK / 4)) * p.ldb + 4 * (tid % (BK / 4)); b_step = BK; b_ist = (int64_t)(NT / (BK / 4)) * p.ldb; }
+    else     { gb = p.B + (int64_t)(tid / (BN / 4)) * p.ldb + n0 + 4 * (tid % (BN / 4)); b_step = (int64_t)BK * p.ldb; b_ist = (int64_t)(NT / (BN / 4)) * p.ldb; }
+
+    // one store "unit" = one float4 register; per-thread LDS offset + compile-time unit offsets
+    const int sa_off = AK ? (4 * (tid % (BK / 4))) * SA + tid / (BK / 4) : (tid / (BM / 4)) * SA + 4 * (tid % (BM / 4));
+    const int sb_off = BKC ? (4 * (tid % (BK / 4))) * SB + tid / (BK / 4) : (tid / (BN / 4)) * SB + 4 * (tid % (BN / 4));
+    auto store_unit = [&](int u, int buf) {
+        if (u < NLA) {
+            float* d = sA + buf * BK * SA + sa_off + (AK ? u * (NT / (BK / 4)) : u * (NT / (BM / 4)) * SA);
+            if (AK) { d[0] = ra[u].x; d[SA] = ra[u].y; d[2 * SA] = ra[u].z; d[3 * SA] = ra[u].w; }
+            else *reinterpret_cast<float4*>(d) = ra[u];
+        } else {
+            const int v = u - NLA;
+            float* d = sB + buf * BK * SB + sb_off + (BKC ? v * (NT / (BK / 4)) : v * (NT / (BN / 4)) * SB);
+            if (BKC) { d[0] = rb[v].x; d[SB] = rb[v].y; d[2 * SB] = rb[v].z; d[3 * SB] = rb[v].w; }
+            else *reinterpret_cast<float4*>(d) = rb[v];
+        }
+    };
+    auto load_unit = [&](int u) {
+        if (u < NLA) ra[u] = *reinterpret_cast<const float4*>(ga + u * a_ist);
+        else rb[u - NLA] = *reinterpret_cast<const float4*>(gb + (u - NLA) * b_ist);
+    };
+
+    // ---- prologue: tile 0
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) load_unit(u);
+    } else {
+        tile_load<AK, BM, VEC>(p.A, p.lda, m0, 0, p.M, p.K, tid, ra);
+        tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, 0, p.N, p.K, tid, rb);
     }
-    tile_store<AK, BM>(sA, tid, ra);
-    tile_store<BKC, BN>(sB, tid, rb);
+    add_colsum();
+#pragma unroll
+    for (int u = 0; u < NL; ++u) store_unit(u, 0);
     __syncthreads();
 
-    int cur = 0;
-    const int lrow = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
+    int cur = 0, kt = 0;
+    if (fast) {
+        // ---- scheduled loop: tile kt computes while full tile kt+1 is fetched and staged
+        for (; kt + 1 < nfull; ++kt) {
+            const float* a_s = a_base + cur * BK * SA;
+            const float* b_s = b_base + cur * BK * SB;
+            ga += a_step;
+            gb += b_step;
+            float af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = a_s[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = b_s[j * 32];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int q_ = kk * NMF + i * TN + j;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                        if (i * TN + j == 0 && kk + 1 < BK / 2) {        // fragments of the next k pair
+#pragma unroll
+                            for (int ii = 0; ii < TM; ++ii) af[(kk + 1) & 1][ii] = a_s[(2 * (kk + 1)) * SA + ii * 32];
+#pragma unroll
+                            for (int jj = 0; jj < TN; ++jj) bf[(kk + 1) & 1][jj] = b_s[(2 * (kk + 1)) * SB + jj * 32];
+                        }
+#pragma unroll
+                        for (int u = 0; u < NL; ++u) {
+                            if (q_ == (u * (Q / 4)) / NL) load_unit(u);                  // first quarter: HBM loads
+                            if (q_ == Q / 2 + (u * (Q / 4)) / NL) {                      // third quarter: LDS stores
+                                if (u == 0) add_colsum();
+                                store_unit(u, cur ^ 1);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // ---- generic loop: edge blocks from tile 0; interior blocks only their last full tile and the K tail
+    for (; kt < nkt; ++kt) {
         const bool more = (kt + 1 < nkt);
         if (more) {
             tile_load<AK, BM, VEC>(p.A, p.lda, m0, (kt + 1) * BK, p.M, p.K, tid, ra);
             tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, (kt + 1) * BK, p.N, p.K, tid, rb);
         }
-        const float* a_s = sA + cur * BK * SA + wm * (BM / 2) + lrow;
-        const float* b_s = sB + cur * BK * SB + wn * (BN / 2) + lrow;
+        const float* a_s = a_base + cur * BK * SA;
+        const float* b_s = b_base + cur * BK * SB;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const int krow = 2 * kk + lk;
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = a_s[krow * SA + i * 32];
+            for (int i = 0; i < TM; ++i) a[i] = a_s[2 * kk * SA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = b_s[krow * SB + j * 32];
+            for (int j = 0; j < TN; ++j) b[j] = b_s[2 * kk * SB + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -191,10 +286,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            if (TA && do_colsum) {
-#pragma unroll
-                for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
-            }
+            add_colsum();
             tile_store<AK, BM>(sA + (cur ^ 1) * BK * SA, tid, ra);
             tile_store<BKC, BN>(sB + (cur ^ 1) * BK * SB, tid, rb);
         }
