@@ -47,6 +47,13 @@ int laed_sgemm(int transA, int transB, int M, int N, int K,
                float* C, int ldc, const float* bias, int accumulate,
                float* colsum_a, int colsum_accumulate, void* stream);
 
+/* Same product with a caller workspace (ws_floats floats, may be NULL): problems with few output tiles and a long K
+ * are split over K so that all 256 CUs work; partial tiles are summed in a fixed order (bitwise reproducible). */
+int laed_sgemm_ws(int transA, int transB, int M, int N, int K,
+                  const float* A, int lda, const float* B, int ldb,
+                  float* C, int ldc, const float* bias, int accumulate,
+                  float* colsum_a, int colsum_accumulate, float* ws, int64_t ws_floats, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Embedding gather / scatter with optional input dropout.
  *   out[r][:] = table[ids[r]][:] * (keep[r][:] ? 1/(1-p) : 0)            (keep == NULL: no dropout)
@@ -78,6 +85,7 @@ int laed_uniform(float* u, int64_t n, uint64_t seed, uint64_t offset, void* stre
  *        dx[T][B][E] (may be NULL), dw_ih[3H][E], dw_hh[3H][H], db_ih[3H], db_hh[3H], dh0[B][H]
  *        gates is overwritten with d(gi); dgh[T][B][3H] is caller-provided workspace.
  *        accumulate_w != 0: weight/bias grads are added to the existing contents.
+ *        ws (ws_floats floats, may be NULL): split-K scratch for small batches (see laed_sgemm_ws).
  * ------------------------------------------------------------------------------------------ */
 int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  const float* h0, int T, int B, int E, int H,
@@ -86,7 +94,7 @@ int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh,
                  const float* hbuf, float* gates, const float* hn,
                  const float* dout, const float* dhT, int T, int B, int E, int H,
                  float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
-                 float* dh0, int accumulate_w, void* stream);
+                 float* dh0, int accumulate_w, float* ws, int64_t ws_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Posterior / Gumbel-softmax latent (rows R = B*y_size, k classes, k <= 64).

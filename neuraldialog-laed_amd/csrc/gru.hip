@@ -105,12 +105,77 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
     };
 
     const int nkt = (H + BK - 1) / BK;
-    load(0);
-    store(0);
-    __syncthreads();
-    int cur = 0;
     const int lrow = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // interior blocks: scheduled loop (see sgemm.hip) -- loads / LDS reads / LDS stores sit in the MFMA issue gaps
+    const bool interior = VEC && (m0 + BR <= B) && (j0 + 32 <= H);
+    const int nfull = H / BK;
+    const bool fast = interior && nfull > 0;
+    constexpr int KS = BK / 2 / WK;            // k pairs per wave per K tile
+    constexpr int Q = 3 * KS;                  // MFMA issue gaps per K tile
+    constexpr int NL = NLH + NLW;
+    const float* gh = p.hprev + (int64_t)(m0 + tid / (BK / 4)) * H + 4 * (tid % (BK / 4));
+    const float* gw = p.w_hh + (int64_t)(j0 + tid / (BK / 4)) * H + 4 * (tid % (BK / 4));
+    const int64_t h_ist = (int64_t)32 * H, w_ist = (int64_t)H * H;   // 32 rows per pass; one gate block per pass
+    const int s_off_h = (4 * (tid % (BK / 4))) * SH + tid / (BK / 4);
+    const int s_off_w = (4 * (tid % (BK / 4))) * SW + tid / (BK / 4);
+    auto load_unit = [&](int u) {
+        if (u < NLH) rh[u] = *reinterpret_cast<const float4*>(gh + u * h_ist);
+        else rw[u - NLH] = *reinterpret_cast<const float4*>(gw + (u - NLH) * w_ist);
+    };
+    auto store_unit = [&](int u, int buf) {
+        if (u < NLH) {
+            float* d = sH + buf * BK * SH + s_off_h + u * 32;
+            d[0] = rh[u].x; d[SH] = rh[u].y; d[2 * SH] = rh[u].z; d[3 * SH] = rh[u].w;
+        } else {
+            const int v = u - NLH;
+            float* d = sW + buf * BK * SW + s_off_w + v * 32;
+            d[0] = rw[v].x; d[SW] = rw[v].y; d[2 * SW] = rw[v].z; d[3 * SW] = rw[v].w;
+        }
+    };
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) load_unit(u);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) store_unit(u, 0);
+    } else {
+        load(0);
+        store(0);
+    }
+    __syncthreads();
+    int cur = 0, kt = 0;
+    if (fast) {
+        for (; kt + 1 < nfull; ++kt) {
+            const float* h_s = sH + cur * BK * SH + wm * 32 + lrow + (2 * wq + lk) * SH;
+            const float* w_s = sW + cur * BK * SW + lrow + (2 * wq + lk) * SW;
+            gh += BK;
+            gw += BK;
+            float af[2], bf[2][3];
+            af[0] = h_s[0];
+            bf[0][0] = w_s[0]; bf[0][1] = w_s[32]; bf[0][2] = w_s[64];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int q_ = ks * 3 + g;
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1], bf[ks & 1][g], acc[g], 0, 0, 0);
+                    if (g == 0 && ks + 1 < KS) {
+                        const int o = 2 * (ks + 1) * WK;
+                        af[(ks + 1) & 1] = h_s[o * SH];
+                        bf[(ks + 1) & 1][0] = w_s[o * SW]; bf[(ks + 1) & 1][1] = w_s[o * SW + 32]; bf[(ks + 1) & 1][2] = w_s[o * SW + 64];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NL; ++u) {
+                        if (q_ == (u * (Q / 4)) / NL) load_unit(u);
+                        if (q_ == (Q >= 32 ? Q / 2 + (u * (Q / 4)) / NL : (Q - NL + u > 0 ? Q - NL + u : 0))) store_unit(u, cur ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    for (; kt < nkt; ++kt) {
         const bool more = kt + 1 < nkt;
         if (more) load((kt + 1) * BK);
         const float* h_s = sH + cur * BK * SH + wm * 32 + lrow;
@@ -192,8 +257,8 @@ int gru_step(const GruStepArgs& a, hipStream_t stream) {
     if (forced_wm == 2) return launch_step<2, 2>(a, vec, stream);
     if (forced_wm == 1) return launch_step<1, 4>(a, vec, stream);
     // widest row tile that still yields >= 256 blocks (one per CU); tiny batches split K over the waves instead
-    if (a.B > 64 && cdiv64(a.B, 128) * jt >= 256) return launch_step<4, 1>(a, vec, stream);
-    if (a.B > 32) return launch_step<2, 2>(a, vec, stream);
+    if (a.B > 64 && cdiv64(a.B, 128) * jt >= 512) return launch_step<4, 1>(a, vec, stream);
+    if (a.B > 32 && cdiv64(a.B, 64) * jt >= 512) return launch_step<2, 2>(a, vec, stream);
     return launch_step<1, 4>(a, vec, stream);
 }
 
@@ -205,6 +270,8 @@ struct GruBwdStepArgs {
     float* gates;         // [B][3H] in: r,z,n ; out: d(gi)
     float* dgh;           // [B][3H] out
     float* dh;            // [B][H] in: carried dh_t (without dout) ; out: dh_t * z
+    const float* parts;   // [nparts][B][H] split-K partials of the previous step's dgh W_hh product (or NULL)
+    int nparts;
     int B, H;
 };
 
@@ -214,6 +281,7 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(GruBwdStepArgs p) {
         const int64_t b = i / p.H;
         const int j = (int)(i - b * p.H);
         float dh = p.dh[i];
+        for (int s_ = 0; s_ < p.nparts; ++s_) dh += p.parts[(int64_t)s_ * n + i];   // fixed order: reproducible
         if (p.dout != nullptr) dh += p.dout[i];
         float* g = p.gates + b * 3 * p.H;
         float* d = p.dgh + b * 3 * p.H;
@@ -227,6 +295,14 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(GruBwdStepArgs p) {
         g[j] = drp; g[p.H + j] = dzp; g[2 * p.H + j] = dnp;
         d[j] = drp; d[p.H + j] = dzp; d[2 * p.H + j] = dnp * r;
         p.dh[i] = dh * z;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_parts_kernel(float* __restrict__ y, const float* __restrict__ parts, int nparts, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = y[i];
+        for (int s_ = 0; s_ < nparts; ++s_) v += parts[(int64_t)s_ * n + i];
+        y[i] = v;
     }
 }
 
@@ -277,7 +353,7 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
                             const float* hbuf, float* gates, const float* hn,
                             const float* dout, const float* dhT, int T, int B, int E, int H,
                             float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
-                            float* dh0, int accumulate_w, void* stream_) {
+                            float* dh0, int accumulate_w, float* ws, int64_t ws_floats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAED_CHECK_ARG(T > 0 && B > 0 && E > 0 && H > 0, "gru_bwd: non-positive dimension");
     LAED_CHECK_ARG(x && w_ih && w_hh && hbuf && gates && hn && dgh && dw_ih && dw_hh && db_ih && db_hh && dh0,
@@ -289,8 +365,12 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
     else e = hipMemsetAsync(dh0, 0, BH * sizeof(float), stream);
     if (e != hipSuccess) return laed_fail((int)e, "gru_bwd: dh init failed");
     const int nblk = (int)((BH + 255) / 256 < 2048 ? (BH + 255) / 256 : 2048);
+    if (ws == nullptr) ws_floats = 0;
+    int nparts = 0;
     for (int t = T - 1; t >= 0; --t) {
         GruBwdStepArgs a;
+        a.parts = ws;
+        a.nparts = nparts;
         a.dout = dout ? dout + (int64_t)t * BH : nullptr;
         a.hprev = hbuf + (int64_t)t * BH;
         a.hn = hn + (int64_t)t * BH;
@@ -302,14 +382,24 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
         hipLaunchKernelGGL(gru_bwd_gates_kernel, dim3(nblk), dim3(256), 0, stream, a);
         LAED_LAUNCH_CHECK("gru_bwd_gates");
         // dh_{t-1} = dh_t * z + dgh_t W_hh      ([B][3H] x [3H][H])
-        LAED_TRY(laed_sgemm_impl(false, false, B, H, 3 * H, a.dgh, 3 * H, w_hh, H, dh0, H, nullptr, true, nullptr, false, stream));
+        //   small batches split K over blocks; the partials are summed by the next step's gate kernel
+        int S = 1;
+        LAED_TRY(laed_sgemm_splitk_impl(false, false, B, H, 3 * H, a.dgh, 3 * H, w_hh, H, dh0, H, nullptr, true, nullptr, false,
+                                        ws, ws_floats, true, &S, stream));
+        nparts = S > 1 ? S : 0;
+    }
+    if (nparts > 0) {
+        hipLaunchKernelGGL(add_parts_kernel, dim3(nblk), dim3(256), 0, stream, dh0, ws, nparts, BH);
+        LAED_LAUNCH_CHECK("add_parts");
     }
     const bool acc = accumulate_w != 0;
     const int TB = T * B;
     // dW_hh[3H][H] = dgh^T[3H][TB] hprev[TB][H] ; db_hh = colsum(dgh)
-    LAED_TRY(laed_sgemm_impl(true, false, 3 * H, H, TB, dgh, 3 * H, hbuf, H, dw_hh, H, nullptr, acc, db_hh, acc, stream));
+    LAED_TRY(laed_sgemm_splitk_impl(true, false, 3 * H, H, TB, dgh, 3 * H, hbuf, H, dw_hh, H, nullptr, acc, db_hh, acc,
+                                    ws, ws_floats, false, nullptr, stream));
     // dW_ih[3H][E] = dgi^T[3H][TB] x[TB][E] ; db_ih = colsum(dgi)
-    LAED_TRY(laed_sgemm_impl(true, false, 3 * H, E, TB, gates, 3 * H, x, E, dw_ih, E, nullptr, acc, db_ih, acc, stream));
+    LAED_TRY(laed_sgemm_splitk_impl(true, false, 3 * H, E, TB, gates, 3 * H, x, E, dw_ih, E, nullptr, acc, db_ih, acc,
+                                    ws, ws_floats, false, nullptr, stream));
     // dx[TB][E] = dgi[TB][3H] W_ih[3H][E]
     if (dx != nullptr)
         LAED_TRY(laed_sgemm_impl(false, false, TB, E, 3 * H, gates, 3 * H, w_ih, E, dx, E, nullptr, false, nullptr, false, stream));

@@ -38,6 +38,15 @@ int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
                     float* C, int64_t ldc, const float* bias, bool accumulate,
                     float* colsum_a, bool colsum_accumulate, hipStream_t stream);
 
+// split-K variant: `ws` (ws_floats floats) lets short-M/N, long-K problems fill the chip.  raw_partials: leave the
+// S partial products in ws[S][M][N] (no bias / accumulate / C write) and report S in *splits_out (S == 1: the
+// product was written to C as usual).
+int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* C, int64_t ldc, const float* bias, bool accumulate,
+                           float* colsum_a, bool colsum_accumulate,
+                           float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream);
+
 int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
                        int B, int H, hipStream_t stream);
 

@@ -44,6 +44,9 @@ struct SgemmArgs {
     int M, N, K;
     int accumulate, colsum_acc;
     int tiles_m, tiles_n;
+    int splitk, kper;      // splitk > 1: block `split` covers K range [split*kper, min(K, (split+1)*kper)) and writes
+    float* ws;             //   its raw partial tile to ws[split][M][N] (colsum partials to ws_colsum[split][M])
+    float* ws_colsum;
 };
 
 constexpr int BK = 32;
@@ -135,6 +138,10 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     int nwg = gridDim.x, pid = blockIdx.x;
     int xcd = pid & 7, q = nwg >> 3, r = nwg & 7;
     int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+    int split = 0;
+    if (p.splitk > 1) { split = wg % p.splitk; wg /= p.splitk; }
+    const int kbeg = split * p.kper;
+    const int kend = (p.splitk > 1) ? min(p.K, kbeg + p.kper) : p.K;
     constexpr int GROUP_M = 8;
     int in_group = GROUP_M * p.tiles_n;
     int gid = wg / in_group, first_m = gid * GROUP_M;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
     const int lrow = lane & 31, lk = lane >> 5;
-    const int nkt = (p.K + BK - 1) / BK;
+    const int nkt = (kend - kbeg + BK - 1) / BK;
     const float* a_base = sA + wm * (BM / 2) + lrow + lk * SA;   // fragment row (2*kk + lk) folded into the base
     const float* b_base = sB + wn * (BN / 2) + lrow + lk * SB;
 
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     // and a wave issues in order, so whatever sits between two MFMAs is hidden).  Edge blocks and the K tail use
     // the generic loop with the guarded loader.
     const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    const int nfull = p.K / BK;          // K tiles that need no K-tail guard
+    const int nfull = (kend - kbeg) / BK;   // K tiles that need no K-tail guard
     const bool fast = interior && nfull > 0;
     constexpr int NMF = TM * TN;         // MFMAs per k pair
     constexpr int Q = (BK / 2) * NMF;    // MFMA issue gaps per K tile
@@ -182,10 +189,10 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     const float* ga;
     const float* gb;
     int64_t a_step, b_step, a_ist, b_ist;
-    if (AK) { ga = p.A + (int64_t)(m0 + tid / (BK / 4)) * p.lda + 4 * (tid % (BK / 4)); a_step = BK; a_ist = (int64_t)(NT / (BK / 4)) * p.lda; }
-    else    { ga = p.A + (int64_t)(tid / (BM / 4)) * p.lda + m0 + 4 * (tid % (BM / 4)); a_step = (int64_t)BK * p.lda; a_ist = (int64_t)(NT / (BM / 4)) * p.lda; }
-    if (BKC) { gb = p.B + (int64_t)(n0 + tid / (BK / 4)) * p.ldb + 4 * (tid % (BK / 4)); b_step = BK; b_ist = (int64_t)(NT / (BK / 4)) * p.ldb; }
-    else     { gb = p.B + (int64_t)(tid / (BN / 4)) * p.ldb + n0 + 4 * (tid % (BN / 4)); b_step = (int64_t)BK * p.ldb; b_ist = (int64_t)(NT / (BN / 4)) * p.ldb; }
+    if (AK) { ga = p.A + (int64_t)(m0 + tid / (BK / 4)) * p.lda + kbeg + 4 * (tid % (BK / 4)); a_step = BK; a_ist = (int64_t)(NT / (BK / 4)) * p.lda; }
+    else    { ga = p.A + (int64_t)(kbeg + tid / (BM / 4)) * p.lda + m0 + 4 * (tid % (BM / 4)); a_step = (int64_t)BK * p.lda; a_ist = (int64_t)(NT / (BM / 4)) * p.lda; }
+    if (BKC) { gb = p.B + (int64_t)(n0 + tid / (BK / 4)) * p.ldb + kbeg + 4 * (tid % (BK / 4)); b_step = BK; b_ist = (int64_t)(NT / (BK / 4)) * p.ldb; }
+    else     { gb = p.B + (int64_t)(kbeg + tid / (BN / 4)) * p.ldb + n0 + 4 * (tid % (BN / 4)); b_step = (int64_t)BK * p.ldb; b_ist = (int64_t)(NT / (BN / 4)) * p.ldb; }
 
     // one store "unit" = one float4 register; per-thread LDS offset + compile-time unit offsets
     const int sa_off = AK ? (4 * (tid % (BK / 4))) * SA + tid / (BK / 4) : (tid / (BM / 4)) * SA + 4 * (tid % (BM / 4));
@@ -212,8 +219,8 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
 #pragma unroll
         for (int u = 0; u < NL; ++u) load_unit(u);
     } else {
-        tile_load<AK, BM, VEC>(p.A, p.lda, m0, 0, p.M, p.K, tid, ra);
-        tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+        tile_load<AK, BM, VEC>(p.A, p.lda, m0, kbeg, p.M, kend, tid, ra);
+        tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, kbeg, p.N, kend, tid, rb);
     }
     add_colsum();
 #pragma unroll
@@ -267,8 +274,8 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     for (; kt < nkt; ++kt) {
         const bool more = (kt + 1 < nkt);
         if (more) {
-            tile_load<AK, BM, VEC>(p.A, p.lda, m0, (kt + 1) * BK, p.M, p.K, tid, ra);
-            tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, (kt + 1) * BK, p.N, p.K, tid, rb);
+            tile_load<AK, BM, VEC>(p.A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, kend, tid, ra);
+            tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, kend, tid, rb);
         }
         const float* a_s = a_base + cur * BK * SA;
         const float* b_s = b_base + cur * BK * SB;
@@ -305,10 +312,14 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (row < p.M && col < p.N) {
-                    float* dst = p.C + (int64_t)row * p.ldc + col;
-                    float v = acc[i][j][e] + bv;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+                    if (p.splitk > 1) {
+                        p.ws[((int64_t)split * p.M + row) * p.N + col] = acc[i][j][e];
+                    } else {
+                        float* dst = p.C + (int64_t)row * p.ldc + col;
+                        float v = acc[i][j][e] + bv;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
@@ -331,8 +342,34 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
 #pragma unroll
                 for (int gg = 0; gg < G; ++gg) s += red[(gg * RQ + (tid >> 2)) * 4 + (tid & 3)];
                 const int m = m0 + tid;
-                if (m < p.M) p.colsum[m] = p.colsum_acc ? p.colsum[m] + s : s;
+                if (m < p.M) {
+                    if (p.splitk > 1) p.ws_colsum[(int64_t)split * p.M + m] = s;
+                    else p.colsum[m] = p.colsum_acc ? p.colsum[m] + s : s;
+                }
             }
+        }
+    }
+}
+
+// C = sum_s ws[s] (+ bias) (+ C); colsum = sum_s ws_colsum[s] (+ colsum).  Fixed summation order: reproducible.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs p) {
+    const int64_t mn = (int64_t)p.M * p.N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += stride) {
+        const int64_t row = i / p.N;
+        const int col = (int)(i - row * p.N);
+        float v = 0.f;
+        for (int sidx = 0; sidx < p.splitk; ++sidx) v += p.ws[(int64_t)sidx * mn + i];
+        if (p.bias != nullptr) v += p.bias[col];
+        float* dst = p.C + row * p.ldc + col;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+    }
+    if (p.colsum != nullptr) {
+        for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += stride) {
+            float v = 0.f;
+            for (int sidx = 0; sidx < p.splitk; ++sidx) v += p.ws_colsum[(int64_t)sidx * p.M + m];
+            p.colsum[m] = p.colsum_acc ? p.colsum[m] + v : v;
         }
     }
 }
@@ -352,7 +389,7 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     SgemmArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
-    int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
+    int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
     if (g_prof_on) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -373,20 +410,57 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
 }
 
 template <bool TA, bool TB>
-int launch_layout(const SgemmArgs& a, bool vec, hipStream_t stream) {
-    const int64_t big_tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const bool big = big_tiles >= 192;   // enough 128x128 tiles to occupy most of the 256 CUs
-    if (big) return vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
-    return vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
+int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream) {
+    const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    const int nkt = (a.K + BK - 1) / BK;
+    // Target >= 512 resident blocks (2 per CU).  Short-M/N problems with a long K get there by splitting K
+    // (needs caller workspace); the partial tiles are summed in a fixed order (reproducible).
+    bool big = t128 >= 192;
+    int S = 1;
+    if (a.ws != nullptr && t128 < 512) {
+        const int64_t per = (int64_t)a.M * a.N + (a.colsum ? a.M : 0);
+        const int cap = (int)(ws_floats / (per > 0 ? per : 1));
+        int want;
+        if (t128 >= 128 && nkt >= 64) { big = true; want = (int)((512 + t128 - 1) / t128); }
+        else { big = false; want = (int)((512 + t64 - 1) / t64); }
+        const int by_k = nkt / 8;                         // keep >= 8 K tiles per split
+        S = want < by_k ? want : by_k;
+        if (S > cap) S = cap;
+        if (S > 16) S = 16;
+        if (S < 1) S = 1;
+        if (S == 1) big = t128 >= 192;
+    }
+    a.splitk = S;
+    a.kper = ((nkt + S - 1) / S) * BK;
+    if (S > 1) {
+        a.ws_colsum = a.ws + (int64_t)S * a.M * a.N;
+        // every split must own at least one K element
+        while (S > 1 && (int64_t)(S - 1) * a.kper >= a.K) { --S; }
+        a.splitk = S;
+        a.ws_colsum = a.ws + (int64_t)S * a.M * a.N;
+    }
+    if (splits_out) *splits_out = S;
+    int st;
+    if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
+    else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
+    if (st != 0 || S == 1 || raw_partials) return st;
+    const int64_t mn = (int64_t)a.M * a.N;
+    const int nb = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, a);
+    LAED_LAUNCH_CHECK("splitk_reduce");
+    return 0;
 }
 
 }   // namespace
 
-int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
-                    const float* A, int64_t lda, const float* B, int64_t ldb,
-                    float* C, int64_t ldc, const float* bias, bool accumulate,
-                    float* colsum_a, bool colsum_accumulate, hipStream_t stream) {
+int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* C, int64_t ldc, const float* bias, bool accumulate,
+                           float* colsum_a, bool colsum_accumulate,
+                           float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream) {
     LAED_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sgemm: negative dimension");
+    if (splits_out) *splits_out = 1;
     if (M == 0 || N == 0) return 0;
     LAED_CHECK_ARG(A && B && C, "sgemm: null matrix pointer");
     LAED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sgemm: leading dimension too small");
@@ -399,10 +473,19 @@ int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
     a.accumulate = accumulate ? 1 : 0;
     a.colsum_acc = colsum_accumulate ? 1 : 0;
     a.tiles_m = a.tiles_n = 0;
+    a.splitk = 1; a.kper = 0; a.ws = ws; a.ws_colsum = nullptr;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    if (!transA && transB) return launch_layout<false, true>(a, vec, stream);
-    if (!transA && !transB) return launch_layout<false, false>(a, vec, stream);
-    return launch_layout<true, false>(a, vec, stream);
+    if (!transA && transB) return launch_layout<false, true>(a, vec, ws_floats, raw_partials, splits_out, stream);
+    if (!transA && !transB) return launch_layout<false, false>(a, vec, ws_floats, raw_partials, splits_out, stream);
+    return launch_layout<true, false>(a, vec, ws_floats, raw_partials, splits_out, stream);
+}
+
+int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, const float* bias, bool accumulate,
+                    float* colsum_a, bool colsum_accumulate, hipStream_t stream) {
+    return laed_sgemm_splitk_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, colsum_a,
+                                  colsum_accumulate, nullptr, 0, false, nullptr, stream);
 }
 
 extern "C" int laed_sgemm(int transA, int transB, int M, int N, int K,
@@ -411,6 +494,15 @@ extern "C" int laed_sgemm(int transA, int transB, int M, int N, int K,
                           float* colsum_a, int colsum_accumulate, void* stream) {
     return laed_sgemm_impl(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate != 0,
                            colsum_a, colsum_accumulate != 0, (hipStream_t)stream);
+}
+
+extern "C" int laed_sgemm_ws(int transA, int transB, int M, int N, int K,
+                             const float* A, int lda, const float* B, int ldb,
+                             float* C, int ldc, const float* bias, int accumulate,
+                             float* colsum_a, int colsum_accumulate, float* ws, int64_t ws_floats, void* stream) {
+    return laed_sgemm_splitk_impl(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate != 0,
+                                  colsum_a, colsum_accumulate != 0, ws, ws ? ws_floats : 0, false, nullptr,
+                                  (hipStream_t)stream);
 }
 
 // ---- profiler C ABI (measurement aid; not part of the compute path)

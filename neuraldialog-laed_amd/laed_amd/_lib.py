@@ -31,7 +31,8 @@ _SIGS = {
     "laed_dropout_keep_mask": ([_p, _i64, _f, _u64, _u64, _p], _i),
     "laed_uniform": ([_p, _i64, _u64, _u64, _p], _i),
     "laed_gru_fwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p], _i),
-    "laed_gru_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p], _i),
+    "laed_gru_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _p], _i),
+    "laed_sgemm_ws": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i64, _p], _i),
     "laed_gumbel_latent_fwd": ([_p, _p, _i64, _i, _f, _i, _p, _p, _p, _p], _i),
     "laed_gumbel_latent_bwd": ([_p, _p, _p, _p, _i64, _i, _f, _p, _p], _i),
     "laed_latent_stats_blocks": ([], _i),

@@ -22,7 +22,7 @@ def _f32c(t):
 # raw wrappers
 # ----------------------------------------------------------------------------------------------
 def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, colsum_out=None,
-          colsum_accumulate=False):
+          colsum_accumulate=False, splitk_ws=True):
     """C = op(A) op(B) (+bias) (+C).  A, B 2-D fp32 (row stride arbitrary, unit column stride)."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -38,10 +38,14 @@ def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=Fals
     for t in (A, B, out, bias, colsum_out):
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise _lib.LaedError("sgemm: operands must be fp32 CUDA tensors")
-    check(lib.laed_sgemm(int(transA), int(transB), M, N, K, vp(A), A.stride(0) if A.shape[0] > 1 else max(A.shape[1], 1),
-                         vp(B), B.stride(0) if B.shape[0] > 1 else max(B.shape[1], 1),
-                         vp(out), out.stride(0) if out.shape[0] > 1 else max(N, 1), vp(bias), int(accumulate),
-                         vp(colsum_out), int(colsum_accumulate), stream()), "laed_sgemm")
+    ws, ws_n = None, 0
+    if splitk_ws and M * N <= (1 << 22) and K >= 2048:      # few output tiles, long K: let the library split K
+        ws_n = 8 * (M * N + M)
+        ws = workspace("sgemm_ws", ws_n, A.device)
+    check(lib.laed_sgemm_ws(int(transA), int(transB), M, N, K, vp(A), A.stride(0) if A.shape[0] > 1 else max(A.shape[1], 1),
+                            vp(B), B.stride(0) if B.shape[0] > 1 else max(B.shape[1], 1),
+                            vp(out), out.stride(0) if out.shape[0] > 1 else max(N, 1), vp(bias), int(accumulate),
+                            vp(colsum_out), int(colsum_accumulate), vp(ws), ws_n, stream()), "laed_sgemm_ws")
     return out
 
 
@@ -242,10 +246,12 @@ class GRUFunction(torch.autograd.Function):
         db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)
         db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32)
+        ws_n = 16 * B * H + 4 * 3 * H * (max(H, E) + 1)            # split-K scratch (small batches only use it)
+        ws = workspace("gru_ws", ws_n, dev)
         # NOTE: overwrites the saved `gates` (r,z,n -> d gi): the tape is single-use, like cuDNN's reserve space
         check(lib.laed_gru_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(hbuf), ptr(gates), ptr(hn), ptr(dout), ptr(dhT),
                                T, B, E, H, ptr(dgh), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), 0,
-                               stream()), "laed_gru_bwd")
+                               ptr(ws), ws_n, stream()), "laed_gru_bwd")
         return dx, dw_ih, dw_hh, db_ih, db_hh, (dh0 if ctx.has_h0 else None)
 
 

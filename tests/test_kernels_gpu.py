@@ -56,6 +56,31 @@ def test_sgemm_layouts(ops, M, N, K):
             assert rel_err(cs.cpu(), A.double().sum(0) + 1.0) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(96, 200, 4096), (512, 1024, 3072), (3072, 200, 5000), (64, 64, 300)])
+def test_sgemm_splitk(ops, M, N, K):
+    """Few output tiles + long K: the library splits K over blocks (caller workspace) and sums partials in order."""
+    for (tA, tB) in ((False, True), (False, False), (True, False)):
+        A = rnd(K, M, seed=1) if tA else rnd(M, K, seed=1)
+        B = rnd(N, K, seed=2) if tB else rnd(K, N, seed=2)
+        bias, C0 = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double() + bias.double() + C0.double()
+        Cd = dev(C0.clone())
+        cs = dev(torch.ones(M)) if tA else None
+        ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, bias=dev(bias), out=Cd, accumulate=True, colsum_out=cs,
+                  colsum_accumulate=True)
+        assert rel_err(Cd.cpu(), ref) < 2e-6, (tA, tB)
+        if tA:
+            assert rel_err(cs.cpu(), A.double().sum(0) + 1.0) < 2e-6
+        # same result (bitwise) on a second run: fixed-order reduction, no atomics
+        Cd2 = dev(C0.clone())
+        ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, bias=dev(bias), out=Cd2, accumulate=True)
+        assert torch.equal(Cd, Cd2)
+        # and equal (to rounding) to the unsplit kernel
+        Cd3 = dev(C0.clone())
+        ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, bias=dev(bias), out=Cd3, accumulate=True, splitk_ws=False)
+        assert rel_err(Cd3.cpu(), ref) < 1e-5      # one K-long fp32 fma chain: more rounding than the split sum
+
+
 def test_sgemm_unaligned_views(ops):
     # leading dimensions that are not multiples of 4 and 4-byte-aligned bases -> scalar-load kernels
     A = rnd(90, 71, seed=5)
@@ -103,7 +128,8 @@ def _gru_case(ops, O, T, B, E, H, with_h0, seed, tol):
 
 
 @pytest.mark.parametrize("T,B,E,H,with_h0", [(5, 6, 16, 32, False), (7, 40, 20, 48, True), (4, 200, 64, 96, True),
-                                             (40, 30, 200, 512, True), (3, 130, 36, 160, False)])
+                                             (40, 30, 200, 512, True), (3, 130, 36, 160, False),
+                                             (3, 100, 32, 256, True), (2, 512, 40, 512, False)])
 def test_gru_fwd_bwd(ops, O, T, B, E, H, with_h0):
     _gru_case(ops, O, T, B, E, H, with_h0, seed=10, tol=1e-5)
 
