@@ -177,12 +177,20 @@ int laed_scale_by_dev(float* y, const float* x, const float* s, int64_t n, void*
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): when enabled, every GEMM launch is bracketed by HIP events
- * on its own stream.  laed_prof_collect waits for them and fills a HOST array of 18 doubles:
+ * on its own stream.  laed_prof_collect waits for them and fills a HOST array of 21 doubles:
  * out[v*3+0..2] = {launches, total ms, total algorithmic flops} for variant v = layout*2 + tile,
  * layout 0 = NT (x W^T), 1 = NN (dy W), 2 = TN (dy^T x); tile 0 = 128x128, 1 = 64x64.
  * ------------------------------------------------------------------------------------------ */
 int laed_prof_enable(int on);
-int laed_prof_collect(double* out_host18);
+int laed_prof_collect(double* out_host21);   /* variant 6 = split-bf16 NT 128x128 (see laed_set_gemm_mode) */
+
+/* GEMM math mode (process-wide; default 0, or LAED_GEMM_MODE=bf16x3 in the environment):
+ *   0 = exact fp32 on v_mfma_f32_32x32x2_f32 everywhere (bit-for-bit an fp32 fma chain)
+ *   1 = K-contiguous (x W^T) products with >= 192 128x128 tiles run as split-bf16 "bf16x3": operands are split
+ *       hi+lo into bf16 on the fly and accumulated in fp32 (a_lo b_hi + a_hi b_lo + a_hi b_hi); ~7x the rounding
+ *       error of fp32 (still ~1e-6 relative on this model's losses), ~2.5x the throughput. */
+int laed_set_gemm_mode(int mode);
+int laed_get_gemm_mode(void);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,10 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
                            float* colsum_a, bool colsum_accumulate,
                            float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream);
 
+int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int64_t ldc, const float* bias, bool accumulate,
+                         int splitk, int kper, float* ws, bool vec, hipStream_t stream);
+
 int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
                        int B, int H, hipStream_t stream);
 

@@ -16,12 +16,15 @@
 
 #include <mutex>
 #include <vector>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
 // ---- optional live profiler (bench.py's roofline leg): HIP events around every GEMM launch, on the launch stream.
 // Off by default; when off the launch path touches none of this.  Variant id = layout*2 + (big tile ? 0 : 1).
 struct ProfRec { hipEvent_t start, stop; double flops; int variant; };
+int g_gemm_mode = -1;   // -1 = not initialised (reads LAED_GEMM_MODE), 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x3) for NT
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
@@ -442,6 +445,29 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     }
     if (splits_out) *splits_out = S;
     int st;
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("LAED_GEMM_MODE");
+        g_gemm_mode = (e != nullptr && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
+    }
+    if (g_gemm_mode == 1 && !TA && TB && big && a.colsum == nullptr) {
+        // opt-in split-bf16 math for the K-contiguous (NT) layout, 128x128 tiles (xgemm.hip)
+        if (g_prof_on) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            ProfRec r;
+            r.start = prof_event();
+            r.stop = prof_event();
+            r.flops = 2.0 * a.M * a.N * a.K;
+            r.variant = 6;
+            (void)hipEventRecord(r.start, stream);
+            st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
+                                      a.splitk, a.kper, a.ws, vec, stream);
+            (void)hipEventRecord(r.stop, stream);
+            g_prof_recs.push_back(r);
+        } else {
+            st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
+                                      a.splitk, a.kper, a.ws, vec, stream);
+        }
+    } else
     if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
     else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
     if (st != 0 || S == 1 || raw_partials) return st;
@@ -505,6 +531,19 @@ extern "C" int laed_sgemm_ws(int transA, int transB, int M, int N, int K,
                                   (hipStream_t)stream);
 }
 
+extern "C" int laed_set_gemm_mode(int mode) {
+    LAED_CHECK_ARG(mode == 0 || mode == 1, "set_gemm_mode: 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x3)");
+    g_gemm_mode = mode;
+    return 0;
+}
+extern "C" int laed_get_gemm_mode(void) {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("LAED_GEMM_MODE");
+        g_gemm_mode = (e != nullptr && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
+    }
+    return g_gemm_mode;
+}
+
 // ---- profiler C ABI (measurement aid; not part of the compute path)
 extern "C" int laed_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -513,10 +552,11 @@ extern "C" int laed_prof_enable(int on) {
 }
 
 // Waits for every recorded launch, then fills out[variant*3 + {0,1,2}] = {launches, total ms, total flops} for the
-// 6 GEMM variants (NT, NN, TN) x (128x128, 64x64) and clears the records.  `out` is a HOST array of 18 doubles.
+// 6 fp32 GEMM variants (NT, NN, TN) x (128x128, 64x64) + variant 6 = split-bf16 NT 128x128, and clears the records.
+// `out` is a HOST array of 21 doubles.
 extern "C" int laed_prof_collect(double* out) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < 18; ++i) out[i] = 0.0;
+    for (int i = 0; i < 21; ++i) out[i] = 0.0;
     for (auto& r : g_prof_recs) {
         float ms = 0.f;
         hipError_t e = hipEventSynchronize(r.stop);

@@ -49,6 +49,8 @@ _SIGS = {
     "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),
     "laed_prof_enable": ([_i], _i),
     "laed_prof_collect": ([ctypes.POINTER(ctypes.c_double)], _i),
+    "laed_set_gemm_mode": ([_i], _i),
+    "laed_get_gemm_mode": ([], _i),
     "laed_dot": ([_p, _p, _i64, _p, _p], _i),
     "laed_gru_decode_greedy": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p], _i),
 }

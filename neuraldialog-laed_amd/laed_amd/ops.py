@@ -49,6 +49,16 @@ def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=Fals
     return out
 
 
+def set_gemm_mode(mode):
+    """'fp32' (default; exact fp32 MFMA) or 'bf16x3' (split-bf16 products, fp32 accumulate) for x W^T GEMMs."""
+    m = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}[mode]
+    check(lib.laed_set_gemm_mode(m), "laed_set_gemm_mode")
+
+
+def get_gemm_mode():
+    return "bf16x3" if lib.laed_get_gemm_mode() == 1 else "fp32"
+
+
 def uniform(n, seed, offset, device):
     u = torch.empty(n, device=device, dtype=torch.float32)
     check(lib.laed_uniform(ptr(u), n, seed, offset, stream()), "laed_uniform")

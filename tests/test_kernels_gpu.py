@@ -81,6 +81,30 @@ def test_sgemm_splitk(ops, M, N, K):
         assert rel_err(Cd3.cpu(), ref) < 1e-5      # one K-long fp32 fma chain: more rounding than the split sum
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 2304, 200), (1536, 2100, 1024), (4000, 1111, 777), (2048, 2048, 4096)])
+def test_xgemm_bf16x3(ops, M, N, K):
+    """Opt-in split-bf16 math mode for x W^T: fp32-grade results (error within ~10x of the exact-fp32 kernel)."""
+    A, B, bias, C0 = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = A.double() @ B.double().t() + bias.double() + C0.double()
+    exact = dev(C0.clone())
+    ops.sgemm(dev(A), dev(B), transB=True, bias=dev(bias), out=exact, accumulate=True)
+    try:
+        ops.set_gemm_mode("bf16x3")
+        assert ops.get_gemm_mode() == "bf16x3"
+        split = dev(C0.clone())
+        ops.sgemm(dev(A), dev(B), transB=True, bias=dev(bias), out=split, accumulate=True)
+        # unaligned leading dimensions -> scalar-load variant of the same kernel
+        Ad, Bd = dev(torch.cat([A, A[:, :1]], 1)), dev(torch.cat([B, B[:, :1]], 1))
+        split2 = ops.sgemm(Ad[:, :K], Bd[:, :K], transB=True, bias=dev(bias))
+    finally:
+        ops.set_gemm_mode("fp32")
+    e_exact, e_split = rel_err(exact.cpu(), ref), rel_err(split.cpu(), ref)
+    assert e_exact < 2e-6
+    assert e_split < 2e-5 and e_split < 20 * max(e_exact, 1e-7), (e_exact, e_split)
+    assert rel_err(split2.cpu(), ref - C0.double()) < 2e-5
+    assert not torch.equal(exact, split)          # the mode switch really selects another kernel
+
+
 def test_sgemm_unaligned_views(ops):
     # leading dimensions that are not multiples of 4 and 4-byte-aligned bases -> scalar-load kernels
     A = rnd(90, 71, seed=5)

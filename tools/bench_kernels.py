@@ -29,6 +29,12 @@ def gemm_case(name, M, N, K, tA, tB):
 if __name__ == "__main__":
     H, V, E = 1024, 50000, 200
     R = 5120
+    ops.set_gemm_mode("bf16x3")
+    gemm_case("bf16x3 logits NT (h W^T)", R, V, H, False, True)
+    gemm_case("bf16x3 square 4096 NT", 4096, 4096, 4096, False, True)
+    gemm_case("bf16x3 square 8192 NT", 8192, 8192, 8192, False, True)
+    gemm_case("bf16x3 gi NT B=4096", 4096 * 40, 3 * H, E, False, True)
+    ops.set_gemm_mode("fp32")
     gemm_case("logits NT (h W^T)", R, V, H, False, True)
     gemm_case("dh NN (dl W)", R, H, V, False, False)
     gemm_case("dW TN (dl^T h)", V, H, R, True, False)
