@@ -135,12 +135,14 @@ int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale,
  *       1/count_global for 'word' averaging) -- multiplies the gradients only.
  *   outputs: tok_nll[N] = lse - logit[label] (0 on ignored rows), lse[N]
  *   if with_grad: dh[N][H] = dL/dh, dW[V][H] (+)=, db[V] (+)= for  L = sum_r row_scale[r]*tok_nll[r]
- *   workspace: chunk_rows*ldl floats, ldl = laed_proj_nll_ldl(V)
+ *   workspace: laed_proj_nll_workspace(H, V, chunk_rows) floats (chunk_rows*ldl, ldl = laed_proj_nll_ldl(V), plus
+ *       fp32 transposed operand copies when the split-bf16 GEMM mode is on)
  * ------------------------------------------------------------------------------------------ */
-int laed_proj_nll_ldl(int V);
+int     laed_proj_nll_ldl(int V);
+int64_t laed_proj_nll_workspace(int H, int V, int chunk_rows);   /* floats needed (depends on the GEMM math mode) */
 int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t* labels, const float* row_scale,
                   int64_t N, int H, int V, int64_t pad_id, int with_grad, int accumulate_w,
-                  float* workspace, int chunk_rows,
+                  float* workspace, int64_t ws_floats, int chunk_rows,
                   float* tok_nll, float* lse, float* dh, float* dW, float* db, void* stream);
 
 /* log-probabilities for callers that really want the [N][V] tensor (DecoderRNN's public contract,

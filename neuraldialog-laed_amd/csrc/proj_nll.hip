@@ -176,15 +176,71 @@ __global__ __launch_bounds__(1024) void dot_kernel(const float* __restrict__ a, 
     }
 }
 
+// dst[c][r] = src[r][c] for a [R][C] fp32 matrix (ld >= C), dst ld = ldd >= R.  One block owns a 64-column strip
+// and walks all rows, so it can also emit the strip's column sums (bias gradient) without atomics:
+// colsum[c] (+)= sum_r src[r][c].  Coalesced 256-byte segments on both sides through a padded LDS tile.
+__global__ __launch_bounds__(256) void transpose_colsum_kernel(const float* __restrict__ src, int64_t ld, int R, int C,
+                                                               float* __restrict__ dst, int64_t ldd,
+                                                               float* __restrict__ colsum, int colsum_acc) {
+    __shared__ float tile[64][65];
+    __shared__ float red[4][64];
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    float csum = 0.f;
+    for (int r0 = 0; r0 < R; r0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + ty + 4 * i, c = c0 + tx;
+            const float v = (r < R && c < C) ? src[(int64_t)r * ld + c] : 0.f;
+            tile[ty + 4 * i][tx] = v;
+            csum += v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + ty + 4 * i, r = r0 + tx;
+            if (c < C && r < R) dst[(int64_t)c * ldd + r] = tile[tx][ty + 4 * i];
+        }
+        __syncthreads();
+    }
+    if (colsum != nullptr) {
+        red[ty][tx] = csum;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) {
+            const float s_ = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+            colsum[c0 + tx] = colsum_acc ? colsum[c0 + tx] + s_ : s_;
+        }
+    }
+}
+
+int transpose_colsum(const float* src, int64_t ld, int R, int C, float* dst, int64_t ldd, float* colsum, bool acc,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(transpose_colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, src, ld, R, C, dst, ldd, colsum,
+                       acc ? 1 : 0);
+    LAED_LAUNCH_CHECK("transpose_colsum");
+    return 0;
+}
+
 inline int rows_grid(int64_t rows) { return (int)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
 
 }   // namespace
 
 extern "C" int laed_proj_nll_ldl(int V) { return (V + 31) / 32 * 32; }
 
+// floats of workspace laed_proj_nll needs for the current GEMM math mode
+extern "C" int64_t laed_proj_nll_workspace(int H, int V, int chunk_rows) {
+    const int64_t ldl = laed_proj_nll_ldl(V);
+    int64_t n = (int64_t)chunk_rows * ldl;
+    if (laed_get_gemm_mode() == 1) {
+        const int64_t ldr = (chunk_rows + 31) / 32 * 32;
+        n += (int64_t)V * ldr + (int64_t)H * ldr + (int64_t)H * ldl;   // dl^T, h^T, W^T (K-contiguous operands)
+    }
+    return n;
+}
+
 extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t* labels, const float* row_scale,
                              int64_t N, int H, int V, int64_t pad_id, int with_grad, int accumulate_w,
-                             float* workspace, int chunk_rows,
+                             float* workspace, int64_t ws_floats, int chunk_rows,
                              float* tok_nll, float* lse, float* dh, float* dW, float* db, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAED_CHECK_ARG(N >= 0 && H > 0 && V > 0 && chunk_rows > 0, "proj_nll: bad size");
@@ -193,7 +249,16 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
     LAED_CHECK_ARG(!with_grad || (dh && dW && db), "proj_nll: with_grad needs dh, dW, db");
     LAED_CHECK_ARG(aligned16(workspace), "proj_nll: workspace must be 16-byte aligned");
     const int64_t ldl = laed_proj_nll_ldl(V);
+    LAED_CHECK_ARG(ws_floats >= laed_proj_nll_workspace(H, V, chunk_rows), "proj_nll: workspace too small (%lld < %lld floats)",
+                   (long long)ws_floats, (long long)laed_proj_nll_workspace(H, V, chunk_rows));
     bool acc = accumulate_w != 0;
+    // split-bf16 mode: every product is brought to the K-contiguous (x W^T) form via fp32 transposed copies
+    const bool xmode = laed_get_gemm_mode() == 1 && with_grad;
+    const int64_t ldr = (chunk_rows + 31) / 32 * 32;
+    float* dlT = workspace + (int64_t)chunk_rows * ldl;   // [V][ldr]
+    float* hT = dlT + (int64_t)V * ldr;                    // [H][ldr]
+    float* WT = hT + (int64_t)H * ldr;                     // [H][ldl]
+    if (xmode) LAED_TRY(transpose_colsum(W, H, V, H, WT, ldl, nullptr, false, stream));
     for (int64_t r0 = 0; r0 < N; r0 += chunk_rows) {
         const int rows = (int)((N - r0) < chunk_rows ? (N - r0) : chunk_rows);
         const float* hc = h + r0 * H;
@@ -205,7 +270,14 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
             hipLaunchKernelGGL((proj_rows_kernel<MODE_STATS>), dim3(rows_grid(rows)), dim3(256), 0, stream, workspace, (int64_t)rows, V,
                                ldl, labels + r0, nullptr, pad_id, tok_nll + r0, lse ? lse + r0 : nullptr);
         LAED_LAUNCH_CHECK("proj_rows");
-        if (with_grad) {
+        if (with_grad && xmode) {
+            // dh = dl W  as  dl [rows][V] x (W^T [H][V])^T ;  dW += dl^T h  as  dl^T [V][rows] x (h^T [H][rows])^T
+            LAED_TRY(laed_sgemm_impl(false, true, rows, H, V, workspace, ldl, WT, ldl, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
+            LAED_TRY(transpose_colsum(workspace, ldl, rows, V, dlT, ldr, db, acc, stream));
+            LAED_TRY(transpose_colsum(hc, H, rows, H, hT, ldr, nullptr, false, stream));
+            LAED_TRY(laed_sgemm_impl(false, true, V, H, rows, dlT, ldr, hT, ldr, dW, H, nullptr, acc, nullptr, false, stream));
+            acc = true;
+        } else if (with_grad) {
             LAED_TRY(laed_sgemm_impl(false, false, rows, H, V, workspace, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
             LAED_TRY(laed_sgemm_impl(true, false, V, H, rows, workspace, ldl, hc, H, dW, H, nullptr, acc, db, acc, stream));
             acc = true;

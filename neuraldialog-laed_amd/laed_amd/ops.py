@@ -120,7 +120,8 @@ def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None)
     dev = h.device
     if chunk_rows is None:
         chunk_rows = proj_chunk_rows(N, V, H)
-    ws = workspace("proj", chunk_rows * proj_ldl(V), dev)
+    ws_n = int(lib.laed_proj_nll_workspace(int(H), int(V), int(chunk_rows)))
+    ws = workspace("proj", ws_n, dev)
     tok = torch.empty(N, device=dev, dtype=torch.float32)
     lse = torch.empty(N, device=dev, dtype=torch.float32)
     dh = dW = db = None
@@ -129,7 +130,7 @@ def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None)
         dW = torch.empty_like(W)
         db = torch.empty(V, device=dev, dtype=torch.float32)
     check(lib.laed_proj_nll(ptr(h), ptr(W), ptr(b), ptr(labels, I64), ptr(row_scale), N, H, V, int(pad_id),
-                            int(with_grad), 0, ptr(ws), int(chunk_rows), ptr(tok), ptr(lse), ptr(dh), ptr(dW), ptr(db),
+                            int(with_grad), 0, ptr(ws), ws_n, int(chunk_rows), ptr(tok), ptr(lse), ptr(dh), ptr(dW), ptr(db),
                             stream()), "laed_proj_nll")
     return tok, lse, dh, dW, db
 

@@ -240,6 +240,28 @@ def test_proj_nll(ops, N, H, V, chunk):
     assert abs(float(red[0]) - float(tok_c.sum())) < 1e-4 * abs(float(tok_c.sum())) and float(red[1]) == cnt
 
 
+def test_proj_nll_bf16x3_mode(ops):
+    """The projection+NLL pipeline under the opt-in split-bf16 GEMM mode (all three products as x W^T on transposed
+    fp32 copies): same answers as the CPU reference to fp32-grade tolerance, two chunks, PAD rows, odd V."""
+    N, H, V, chunk = 3000, 160, 8203, 2048
+    h, W, b = rnd(N, H, seed=1), rnd(V, H, seed=2, scale=0.3), rnd(V, seed=3, scale=0.1)
+    labels = torch.randint(1, V, (N,), generator=torch.Generator().manual_seed(4))
+    labels[::7] = 0
+    cnt = float((labels != 0).sum())
+    hc, Wc, bc = (t.clone().requires_grad_(True) for t in (h, W, b))
+    logp = torch.log_softmax(hc @ Wc.t() + bc, dim=1)
+    torch.nn.functional.nll_loss(logp, labels, ignore_index=0).backward()
+    tok_c = -logp.detach().gather(1, labels.view(-1, 1)).view(-1) * (labels != 0)
+    try:
+        ops.set_gemm_mode("bf16x3")
+        tok, lse, dh, dW, db = ops.proj_nll_raw(dev(h), dev(W), dev(b), dev(labels), dev(torch.full((N,), 1.0 / cnt)), 0,
+                                                True, chunk)
+    finally:
+        ops.set_gemm_mode("fp32")
+    assert rel_err(tok.cpu(), tok_c) < 2e-5
+    assert rel_err(dh.cpu(), hc.grad) < 5e-5 and rel_err(dW.cpu(), Wc.grad) < 5e-5 and rel_err(db.cpu(), bc.grad) < 1e-5
+
+
 def test_embed_gather_scatter(ops):
     V, E, rows = 57, 24, 200
     table = rnd(V, E, seed=1)
