@@ -87,6 +87,7 @@ int laed_uniform(float* u, int64_t n, uint64_t seed, uint64_t offset, void* stre
  *        accumulate_w != 0: weight/bias grads are added to the existing contents.
  *        ws (ws_floats floats, may be NULL): split-K scratch for small batches (see laed_sgemm_ws).
  * ------------------------------------------------------------------------------------------ */
+int64_t laed_gru_bwd_workspace(int T, int B, int E, int H);   /* recommended ws_floats for laed_gru_bwd */
 int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  const float* h0, int T, int B, int E, int H,
                  float* hbuf, float* gates, float* hn, void* stream);
@@ -192,6 +193,7 @@ int laed_prof_collect(double* out_host21);   /* variant 6 = split-bf16 NT 128x12
  *       hi+lo into bf16 on the fly and accumulated in fp32 (a_lo b_hi + a_hi b_lo + a_hi b_hi); ~7x the rounding
  *       error of fp32 (still ~1e-6 relative on this model's losses), ~2.5x the throughput. */
 int laed_set_gemm_mode(int mode);
+int laed_set_xgemm_min_tiles(int n);   /* test hook: minimum 128x128 tile count for mode 1 to apply (default 192) */
 int laed_get_gemm_mode(void);
 
 #ifdef __cplusplus

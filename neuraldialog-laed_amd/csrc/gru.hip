@@ -308,6 +308,14 @@ __global__ __launch_bounds__(256) void add_parts_kernel(float* __restrict__ y, c
 
 }   // namespace
 
+extern "C" int64_t laed_gru_bwd_workspace(int T, int B, int E, int H) {
+    const int64_t TBp = ((int64_t)T * B + 31) / 32 * 32;
+    int64_t n = (int64_t)16 * B * H + (int64_t)4 * 3 * H * ((H > E ? H : E) + 1);          // split-K scratch
+    if (laed_get_gemm_mode() == 1)
+        n += (int64_t)3 * H * H + (int64_t)3 * H * E + (int64_t)3 * H * TBp + (int64_t)H * TBp;   // transposed operands
+    return n;
+}
+
 int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
                        int B, int H, hipStream_t stream) {
     GruStepArgs a;
@@ -366,6 +374,20 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
     if (e != hipSuccess) return laed_fail((int)e, "gru_bwd: dh init failed");
     const int nblk = (int)((BH + 255) / 256 < 2048 ? (BH + 255) / 256 : 2048);
     if (ws == nullptr) ws_floats = 0;
+    // split-bf16 mode: bring the big products to the K-contiguous (x W^T) form with transposed fp32 copies carved
+    // from the END of the workspace (the front stays split-K scratch)
+    const int64_t TBp = ((int64_t)T * B + 31) / 32 * 32;
+    const int64_t xneed = (int64_t)3 * H * H + (int64_t)3 * H * E + (int64_t)3 * H * TBp + (int64_t)H * TBp;
+    const bool xmode = laed_get_gemm_mode() == 1 && ws_floats >= xneed + (int64_t)4 * B * H;
+    float *WhhT = nullptr, *WihT = nullptr, *dghT = nullptr, *hT = nullptr;
+    if (xmode) {
+        ws_floats -= xneed;
+        WhhT = ws + ws_floats;              // [H][3H]
+        WihT = WhhT + (int64_t)3 * H * H;   // [E][3H]
+        dghT = WihT + (int64_t)3 * H * E;   // [3H][TBp]
+        hT = dghT + (int64_t)3 * H * TBp;   // [H][TBp]
+        LAED_TRY(laed_transpose_impl(w_hh, H, 3 * H, H, WhhT, 3 * H, stream));
+    }
     int nparts = 0;
     for (int t = T - 1; t >= 0; --t) {
         GruBwdStepArgs a;
@@ -384,8 +406,12 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
         // dh_{t-1} = dh_t * z + dgh_t W_hh      ([B][3H] x [3H][H])
         //   small batches split K over blocks; the partials are summed by the next step's gate kernel
         int S = 1;
-        LAED_TRY(laed_sgemm_splitk_impl(false, false, B, H, 3 * H, a.dgh, 3 * H, w_hh, H, dh0, H, nullptr, true, nullptr, false,
-                                        ws, ws_floats, true, &S, stream));
+        if (xmode)
+            LAED_TRY(laed_sgemm_splitk_impl(false, true, B, H, 3 * H, a.dgh, 3 * H, WhhT, 3 * H, dh0, H, nullptr, true, nullptr,
+                                            false, ws, ws_floats, true, &S, stream));
+        else
+            LAED_TRY(laed_sgemm_splitk_impl(false, false, B, H, 3 * H, a.dgh, 3 * H, w_hh, H, dh0, H, nullptr, true, nullptr,
+                                            false, ws, ws_floats, true, &S, stream));
         nparts = S > 1 ? S : 0;
     }
     if (nparts > 0) {
@@ -395,13 +421,25 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
     const bool acc = accumulate_w != 0;
     const int TB = T * B;
     // dW_hh[3H][H] = dgh^T[3H][TB] hprev[TB][H] ; db_hh = colsum(dgh)
-    LAED_TRY(laed_sgemm_splitk_impl(true, false, 3 * H, H, TB, dgh, 3 * H, hbuf, H, dw_hh, H, nullptr, acc, db_hh, acc,
-                                    ws, ws_floats, false, nullptr, stream));
+    if (xmode) {
+        LAED_TRY(laed_transpose_impl(dgh, 3 * H, TB, 3 * H, dghT, TBp, stream));
+        LAED_TRY(laed_transpose_impl(hbuf, H, TB, H, hT, TBp, stream));
+        LAED_TRY(laed_sgemm_rowsum_impl(3 * H, H, TB, dghT, TBp, hT, TBp, dw_hh, H, acc, db_hh, acc, ws, ws_floats, stream));
+    } else {
+        LAED_TRY(laed_sgemm_splitk_impl(true, false, 3 * H, H, TB, dgh, 3 * H, hbuf, H, dw_hh, H, nullptr, acc, db_hh, acc,
+                                        ws, ws_floats, false, nullptr, stream));
+    }
     // dW_ih[3H][E] = dgi^T[3H][TB] x[TB][E] ; db_ih = colsum(dgi)
     LAED_TRY(laed_sgemm_splitk_impl(true, false, 3 * H, E, TB, gates, 3 * H, x, E, dw_ih, E, nullptr, acc, db_ih, acc,
                                     ws, ws_floats, false, nullptr, stream));
     // dx[TB][E] = dgi[TB][3H] W_ih[3H][E]
-    if (dx != nullptr)
-        LAED_TRY(laed_sgemm_impl(false, false, TB, E, 3 * H, gates, 3 * H, w_ih, E, dx, E, nullptr, false, nullptr, false, stream));
+    if (dx != nullptr) {
+        if (xmode) {
+            LAED_TRY(laed_transpose_impl(w_ih, E, 3 * H, E, WihT, 3 * H, stream));
+            LAED_TRY(laed_sgemm_impl(false, true, TB, E, 3 * H, gates, 3 * H, WihT, 3 * H, dx, E, nullptr, false, nullptr, false, stream));
+        } else {
+            LAED_TRY(laed_sgemm_impl(false, false, TB, E, 3 * H, gates, 3 * H, w_ih, E, dx, E, nullptr, false, nullptr, false, stream));
+        }
+    }
     return 0;
 }

@@ -50,7 +50,13 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
 extern "C" int laed_get_gemm_mode(void);
 int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float* C, int64_t ldc, const float* bias, bool accumulate,
-                         int splitk, int kper, float* ws, bool vec, hipStream_t stream);
+                         int splitk, int kper, float* ws, bool vec, float* rowsum_a, bool rowsum_acc, hipStream_t stream);
+
+int laed_transpose_impl(const float* src, int64_t ld, int R, int C, float* dst, int64_t ldd, hipStream_t stream);
+// C[M,N] (+)= A[M,K] B[N,K]^T and rowsum[m] (+)= sum_k A[m][k], in the current GEMM math mode
+int laed_sgemm_rowsum_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* C, int64_t ldc, bool accumulate, float* rowsum, bool rowsum_acc,
+                           float* ws, int64_t ws_floats, hipStream_t stream);
 
 int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
                        int B, int H, hipStream_t stream);

@@ -176,50 +176,54 @@ __global__ __launch_bounds__(1024) void dot_kernel(const float* __restrict__ a, 
     }
 }
 
-// dst[c][r] = src[r][c] for a [R][C] fp32 matrix (ld >= C), dst ld = ldd >= R.  One block owns a 64-column strip
-// and walks all rows, so it can also emit the strip's column sums (bias gradient) without atomics:
-// colsum[c] (+)= sum_r src[r][c].  Coalesced 256-byte segments on both sides through a padded LDS tile.
-__global__ __launch_bounds__(256) void transpose_colsum_kernel(const float* __restrict__ src, int64_t ld, int R, int C,
-                                                               float* __restrict__ dst, int64_t ldd,
-                                                               float* __restrict__ colsum, int colsum_acc) {
+// dst[c][r] = src[r][c] for a [R][C] fp32 matrix (row stride ld), dst row stride ldd.  64x64 tiles through a
+// padded LDS tile, float4 (16-byte) accesses on both sides when alignment allows: HBM-bound.
+template <bool VEC>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t ld, int R, int C,
+                                                        float* __restrict__ dst, int64_t ldd) {
     __shared__ float tile[64][65];
-    __shared__ float red[4][64];
-    const int c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
-    float csum = 0.f;
-    for (int r0 = 0; r0 < R; r0 += 64) {
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tq = threadIdx.x & 15, tr = threadIdx.x >> 4;   // 16 float4 columns x 16 rows per pass
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = r0 + ty + 4 * i, c = c0 + tx;
-            const float v = (r < R && c < C) ? src[(int64_t)r * ld + c] : 0.f;
-            tile[ty + 4 * i][tx] = v;
-            csum += v;
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + tr + 16 * i, c = c0 + 4 * tq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            const float* sp = src + (int64_t)r * ld + c;
+            if (VEC && c + 3 < C) v = *reinterpret_cast<const float4*>(sp);
+            else { if (c < C) v.x = sp[0]; if (c + 1 < C) v.y = sp[1]; if (c + 2 < C) v.z = sp[2]; if (c + 3 < C) v.w = sp[3]; }
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = c0 + ty + 4 * i, r = r0 + tx;
-            if (c < C && r < R) dst[(int64_t)c * ldd + r] = tile[tx][ty + 4 * i];
-        }
-        __syncthreads();
+        float* t = &tile[tr + 16 * i][4 * tq];
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     }
-    if (colsum != nullptr) {
-        red[ty][tx] = csum;
-        __syncthreads();
-        if (ty == 0 && c0 + tx < C) {
-            const float s_ = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-            colsum[c0 + tx] = colsum_acc ? colsum[c0 + tx] + s_ : s_;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + tr + 16 * i, r = r0 + 4 * tq;   // dst row c, 4 consecutive r
+        if (c < C && r < R) {
+            const int lc = tr + 16 * i, lr = 4 * tq;
+            float4 v = make_float4(tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+            float* dp = dst + (int64_t)c * ldd + r;
+            if (VEC && r + 3 < R) *reinterpret_cast<float4*>(dp) = v;
+            else { dp[0] = v.x; if (r + 1 < R) dp[1] = v.y; if (r + 2 < R) dp[2] = v.z; if (r + 3 < R) dp[3] = v.w; }
         }
     }
 }
 
-int transpose_colsum(const float* src, int64_t ld, int R, int C, float* dst, int64_t ldd, float* colsum, bool acc,
-                     hipStream_t stream) {
-    hipLaunchKernelGGL(transpose_colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, src, ld, R, C, dst, ldd, colsum,
-                       acc ? 1 : 0);
-    LAED_LAUNCH_CHECK("transpose_colsum");
+}   // namespace
+
+int laed_transpose_impl(const float* src, int64_t ld, int R, int C, float* dst, int64_t ldd, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return 0;
+    const bool vec = aligned16(src) && aligned16(dst) && (ld % 4 == 0) && (ldd % 4 == 0);
+    dim3 grid((C + 63) / 64, (R + 63) / 64);
+    if (grid.y > 65535) return laed_fail(LAED_E_SIZE, "transpose: too many rows (%d)", R);
+    if (vec) hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, stream, src, ld, R, C, dst, ldd);
+    else hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, stream, src, ld, R, C, dst, ldd);
+    LAED_LAUNCH_CHECK("transpose");
     return 0;
 }
+
+namespace {
 
 inline int rows_grid(int64_t rows) { return (int)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
 
@@ -258,7 +262,7 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
     float* dlT = workspace + (int64_t)chunk_rows * ldl;   // [V][ldr]
     float* hT = dlT + (int64_t)V * ldr;                    // [H][ldr]
     float* WT = hT + (int64_t)H * ldr;                     // [H][ldl]
-    if (xmode) LAED_TRY(transpose_colsum(W, H, V, H, WT, ldl, nullptr, false, stream));
+    if (xmode) LAED_TRY(laed_transpose_impl(W, H, V, H, WT, ldl, stream));
     for (int64_t r0 = 0; r0 < N; r0 += chunk_rows) {
         const int rows = (int)((N - r0) < chunk_rows ? (N - r0) : chunk_rows);
         const float* hc = h + r0 * H;
@@ -273,9 +277,10 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
         if (with_grad && xmode) {
             // dh = dl W  as  dl [rows][V] x (W^T [H][V])^T ;  dW += dl^T h  as  dl^T [V][rows] x (h^T [H][rows])^T
             LAED_TRY(laed_sgemm_impl(false, true, rows, H, V, workspace, ldl, WT, ldl, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
-            LAED_TRY(transpose_colsum(workspace, ldl, rows, V, dlT, ldr, db, acc, stream));
-            LAED_TRY(transpose_colsum(hc, H, rows, H, hT, ldr, nullptr, false, stream));
-            LAED_TRY(laed_sgemm_impl(false, true, V, H, rows, dlT, ldr, hT, ldr, dW, H, nullptr, acc, nullptr, false, stream));
+            LAED_TRY(laed_transpose_impl(workspace, ldl, rows, V, dlT, ldr, stream));
+            LAED_TRY(laed_transpose_impl(hc, H, rows, H, hT, ldr, stream));
+            //   db = row sums of dl^T, taken from the A-operand registers of the same GEMM
+            LAED_TRY(laed_sgemm_rowsum_impl(V, H, rows, dlT, ldr, hT, ldr, dW, H, acc, db, acc, nullptr, 0, stream));
             acc = true;
         } else if (with_grad) {
             LAED_TRY(laed_sgemm_impl(false, false, rows, H, V, workspace, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr, false, stream));

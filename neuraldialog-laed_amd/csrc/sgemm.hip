@@ -24,6 +24,7 @@ namespace {
 // ---- optional live profiler (bench.py's roofline leg): HIP events around every GEMM launch, on the launch stream.
 // Off by default; when off the launch path touches none of this.  Variant id = layout*2 + (big tile ? 0 : 1).
 struct ProfRec { hipEvent_t start, stop; double flops; int variant; };
+int64_t g_xgemm_min_tiles = 192;   // bf16x3 mode: NT problems with at least this many 128x128 tiles use xgemm
 int g_gemm_mode = -1;   // -1 = not initialised (reads LAED_GEMM_MODE), 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x3) for NT
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -417,27 +418,31 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
     const int nkt = (a.K + BK - 1) / BK;
+    if (g_gemm_mode < 0) (void)laed_get_gemm_mode();
+    // opt-in split-bf16 math for the K-contiguous (NT) layout, 128x128 tiles (xgemm.hip).  An NT call that asks for
+    // sums over K of A (colsum) can only be served by that kernel and forces it.
+    const bool force_x = !TA && TB && a.colsum != nullptr;
+    const bool use_x = g_gemm_mode == 1 && !TA && TB && (force_x || t128 >= g_xgemm_min_tiles);
     // Target >= 512 resident blocks (2 per CU).  Short-M/N problems with a long K get there by splitting K
     // (needs caller workspace); the partial tiles are summed in a fixed order (reproducible).
-    bool big = t128 >= 192;
+    bool big = use_x || t128 >= 192;
     int S = 1;
     if (a.ws != nullptr && t128 < 512) {
         const int64_t per = (int64_t)a.M * a.N + (a.colsum ? a.M : 0);
         const int cap = (int)(ws_floats / (per > 0 ? per : 1));
         int want;
-        if (t128 >= 128 && nkt >= 64) { big = true; want = (int)((512 + t128 - 1) / t128); }
+        if (use_x || (t128 >= 128 && nkt >= 64)) { big = true; want = (int)((512 + t128 - 1) / t128); }
         else { big = false; want = (int)((512 + t64 - 1) / t64); }
         const int by_k = nkt / 8;                         // keep >= 8 K tiles per split
         S = want < by_k ? want : by_k;
         if (S > cap) S = cap;
         if (S > 16) S = 16;
         if (S < 1) S = 1;
-        if (S == 1) big = t128 >= 192;
+        if (S == 1) big = use_x || t128 >= 192;
     }
     a.splitk = S;
     a.kper = ((nkt + S - 1) / S) * BK;
     if (S > 1) {
-        a.ws_colsum = a.ws + (int64_t)S * a.M * a.N;
         // every split must own at least one K element
         while (S > 1 && (int64_t)(S - 1) * a.kper >= a.K) { --S; }
         a.splitk = S;
@@ -445,30 +450,24 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     }
     if (splits_out) *splits_out = S;
     int st;
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("LAED_GEMM_MODE");
-        g_gemm_mode = (e != nullptr && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
-    }
-    if (g_gemm_mode == 1 && !TA && TB && big && a.colsum == nullptr) {
-        // opt-in split-bf16 math for the K-contiguous (NT) layout, 128x128 tiles (xgemm.hip)
+    if (use_x) {
+        ProfRec r;
         if (g_prof_on) {
             std::lock_guard<std::mutex> lk(g_prof_mu);
-            ProfRec r;
             r.start = prof_event();
             r.stop = prof_event();
             r.flops = 2.0 * a.M * a.N * a.K;
             r.variant = 6;
             (void)hipEventRecord(r.start, stream);
-            st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
-                                      a.splitk, a.kper, a.ws, vec, stream);
+        }
+        st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
+                                  a.splitk, a.kper, a.ws, vec, S > 1 ? a.ws_colsum : a.colsum, a.colsum_acc != 0, stream);
+        if (g_prof_on) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
             (void)hipEventRecord(r.stop, stream);
             g_prof_recs.push_back(r);
-        } else {
-            st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
-                                      a.splitk, a.kper, a.ws, vec, stream);
         }
-    } else
-    if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
+    } else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
     else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
     if (st != 0 || S == 1 || raw_partials) return st;
     const int64_t mn = (int64_t)a.M * a.N;
@@ -491,7 +490,8 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
     LAED_CHECK_ARG(A && B && C, "sgemm: null matrix pointer");
     LAED_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sgemm: leading dimension too small");
     LAED_CHECK_ARG(!(transA && transB), "sgemm: transA && transB not supported");
-    LAED_CHECK_ARG(colsum_a == nullptr || transA, "sgemm: colsum_a needs transA");
+    LAED_CHECK_ARG(colsum_a == nullptr || transA || (transB && laed_get_gemm_mode() == 1),
+                   "sgemm: sums over K of A need transA (or the x W^T layout in the bf16x3 mode)");
     SgemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.colsum = colsum_a;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -504,6 +504,15 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
     if (!transA && transB) return launch_layout<false, true>(a, vec, ws_floats, raw_partials, splits_out, stream);
     if (!transA && !transB) return launch_layout<false, false>(a, vec, ws_floats, raw_partials, splits_out, stream);
     return launch_layout<true, false>(a, vec, ws_floats, raw_partials, splits_out, stream);
+}
+
+// NT product with row sums of A (bf16x3 mode only: the split-bf16 kernel sums its own A-operand registers).
+int laed_sgemm_rowsum_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* C, int64_t ldc, bool accumulate, float* rowsum, bool rowsum_acc,
+                           float* ws, int64_t ws_floats, hipStream_t stream) {
+    LAED_CHECK_ARG(rowsum != nullptr && laed_get_gemm_mode() == 1, "sgemm_rowsum: only available in the bf16x3 mode");
+    return laed_sgemm_splitk_impl(false, true, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, rowsum, rowsum_acc,
+                                  ws, ws_floats, false, nullptr, stream);
 }
 
 int laed_sgemm_impl(bool transA, bool transB, int M, int N, int K,
@@ -529,6 +538,12 @@ extern "C" int laed_sgemm_ws(int transA, int transB, int M, int N, int K,
     return laed_sgemm_splitk_impl(transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate != 0,
                                   colsum_a, colsum_accumulate != 0, ws, ws ? ws_floats : 0, false, nullptr,
                                   (hipStream_t)stream);
+}
+
+extern "C" int laed_set_xgemm_min_tiles(int n) {   // test hook: let small problems take the split-bf16 kernel too
+    LAED_CHECK_ARG(n >= 1, "set_xgemm_min_tiles: n >= 1");
+    g_xgemm_min_tiles = n;
+    return 0;
 }
 
 extern "C" int laed_set_gemm_mode(int mode) {

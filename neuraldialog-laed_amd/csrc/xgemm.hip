@@ -79,6 +79,8 @@ struct XArgs {
     int tiles_m, tiles_n;
     int splitk, kper;
     float* ws;
+    float* rowsum;      // optional: rowsum[m] (+)= sum_k A[m][k]  (tile_n == 0 blocks; split-K: partials [S][M])
+    int rowsum_acc;
 };
 
 template <bool VEC>
@@ -112,6 +114,14 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(XArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[NL], rb[NL];
+    float rsum[NL] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (p.rowsum != nullptr) && (tile_n == 0);
+    auto add_rowsum = [&]() {
+        if (do_rowsum) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) rsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+        }
+    };
     const int nkt = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
     const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);
@@ -144,6 +154,7 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(XArgs p) {
         tile_load<VEC>(p.A, p.lda, m0, kbeg, p.M, kend, tid, ra);
         tile_load<VEC>(p.B, p.ldb, n0, kbeg, p.N, kend, tid, rb);
     }
+    add_rowsum();
 #pragma unroll
     for (int u = 0; u < 2 * NL; ++u) store_unit(u, 0);
     __syncthreads();
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(XArgs p) {
                             else XMFMA(fa[s][i][0], fb[s][j][0], acc[i][j]);               // hi * hi
                             if (s == 0 && q_ == 1) read_frags(cur, 1, fa[1], fb[1]);
                             if (q_ < 2 * NL) load_unit(q_);                                 // gaps 0..7: HBM loads
+                            if (q_ == Q - 2 * NL - 2) add_rowsum();
                             if (q_ >= Q - 2 * NL - 2 && q_ < Q - 2) store_unit(q_ - (Q - 2 * NL - 2), cur ^ 1);   // gaps 14..21
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(XArgs p) {
                 }
         }
         if (more) {
+            add_rowsum();
 #pragma unroll
             for (int u = 0; u < 2 * NL; ++u) store_unit(u, cur ^ 1);
         }
@@ -248,6 +261,20 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(XArgs p) {
             }
         }
     }
+    if (do_rowsum) {   // block-uniform; the 8 lanes tid%8 = 0..7 of a row are adjacent lanes of one wave
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            float v = rsum[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            const int row = m0 + tid / 8 + 32 * i;
+            if ((tid & 7) == 0 && row < p.M) {
+                if (p.splitk > 1) p.rowsum[(int64_t)split * p.M + row] = v;          // partial: summed by the reduce kernel
+                else p.rowsum[row] = p.rowsum_acc ? p.rowsum[row] + v : v;
+            }
+        }
+    }
 }
 
 }   // namespace
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(NT, 2) void xgemm_kernel(XArgs p) {
 // caller (sgemm.hip) runs the reduce kernel.
 int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float* C, int64_t ldc, const float* bias, bool accumulate,
-                         int splitk, int kper, float* ws, bool vec, hipStream_t stream) {
+                         int splitk, int kper, float* ws, bool vec, float* rowsum_a, bool rowsum_acc, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * 2 * OPER * 16;
     static bool attr_set[2] = {false, false};
     const void* kern = vec ? reinterpret_cast<const void*>(xgemm_kernel<true>) : reinterpret_cast<const void*>(xgemm_kernel<false>);
@@ -273,6 +300,8 @@ int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     p.splitk = splitk; p.kper = kper; p.ws = ws;
+    p.rowsum = rowsum_a; p.rowsum_acc = rowsum_acc ? 1 : 0;
+
     const int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (splitk > 1 ? splitk : 1);
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "xgemm: grid %lld out of range", (long long)grid);
     if (vec) hipLaunchKernelGGL(xgemm_kernel<true>, dim3((unsigned)grid), dim3(NT), lds, stream, p);

@@ -32,6 +32,7 @@ _SIGS = {
     "laed_uniform": ([_p, _i64, _u64, _u64, _p], _i),
     "laed_gru_fwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p], _i),
     "laed_gru_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _p], _i),
+    "laed_gru_bwd_workspace": ([_i, _i, _i, _i], _i64),
     "laed_sgemm_ws": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i64, _p], _i),
     "laed_gumbel_latent_fwd": ([_p, _p, _i64, _i, _f, _i, _p, _p, _p, _p], _i),
     "laed_gumbel_latent_bwd": ([_p, _p, _p, _p, _i64, _i, _f, _p, _p], _i),
@@ -52,6 +53,7 @@ _SIGS = {
     "laed_prof_collect": ([ctypes.POINTER(ctypes.c_double)], _i),
     "laed_set_gemm_mode": ([_i], _i),
     "laed_get_gemm_mode": ([], _i),
+    "laed_set_xgemm_min_tiles": ([_i], _i),
     "laed_dot": ([_p, _p, _i64, _p, _p], _i),
     "laed_gru_decode_greedy": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p], _i),
 }

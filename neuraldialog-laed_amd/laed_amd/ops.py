@@ -257,7 +257,7 @@ class GRUFunction(torch.autograd.Function):
         db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)
         db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32)
-        ws_n = 16 * B * H + 4 * 3 * H * (max(H, E) + 1)            # split-K scratch (small batches only use it)
+        ws_n = int(lib.laed_gru_bwd_workspace(T, B, E, H))         # split-K scratch (+ transposed operands in bf16x3 mode)
         ws = workspace("gru_ws", ws_n, dev)
         # NOTE: overwrites the saved `gates` (r,z,n -> d gi): the tape is single-use, like cuDNN's reserve space
         check(lib.laed_gru_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(hbuf), ptr(gates), ptr(hn), ptr(dout), ptr(dhT),
