@@ -1,0 +1,113 @@
+"""The train/validate engine (laed_amd.main, mirror of laed/main.py) on the HIP model: loss goes down on a toy
+corpus, the best-valid checkpoint is written with the reference's state_dict keys and reloads, and the
+RnnUttEncoder (bi-directional GRU + attention pooling, used by AE-ED/ST-ED) matches the reference goldens."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+class Feed(object):
+    """Minimal loader with the reference's interface (dataloader_bases.py:29-56): fixed batches of int32 ids."""
+
+    def __init__(self, name, data, batch_size):
+        self.name, self.data, self.batch_size = name, data, batch_size
+        self.ptr = 0
+
+    def epoch_init(self, config, shuffle=True, verbose=True):
+        self.ptr = 0
+        self.num_batch = len(self.data) // self.batch_size
+
+    def next_batch(self):
+        if self.ptr >= self.num_batch:
+            return None
+        rows = self.data[self.ptr * self.batch_size:(self.ptr + 1) * self.batch_size]
+        self.ptr += 1
+        return {"outputs": rows, "output_lens": [rows.shape[1]] * rows.shape[0]}
+
+
+def test_train_validate_checkpoint(tmp_path):
+    from laed_amd import main as engine
+    from laed_amd.models.sent_models import DiVAE
+    V, T = 40, 9
+    rs = np.random.RandomState(0)
+    # a corpus with structure: token t+1 = (token t + 1) mod, so the decoder can learn it
+    starts = rs.randint(4, V, size=(120, 1))
+    body = (starts + np.arange(T - 2)[None, :] - 4) % (V - 4) + 4
+    data = np.concatenate([np.full((120, 1), 2), body, np.full((120, 1), 3)], axis=1).astype(np.int32)
+
+    class Corpus(object):
+        vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
+        rev_vocab = {w: i for i, w in enumerate(vocab)}
+
+    cfg = Namespace(embed_size=16, max_utt_len=T, num_layer=1, dropout=0.3, enc_cell_size=32, dec_cell_size=32,
+                    rnn_cell='gru', max_dec_len=T, use_attn=False, beam_size=4, utt_type='rnn', bi_enc_cell=False,
+                    attn_type='cat', fix_batch=False, y_size=3, k=5, use_gpu=True, avg_type='word', use_mutual=True,
+                    use_reg_kl=True, train_prior=False, init_lr=0.01, op='adam', print_step=10, ckpt_step=20,
+                    max_epoch=4, early_stop=True, improve_threshold=0.996, patient_increase=2.0, save_model=True,
+                    session_dir=str(tmp_path), preview_batch_num=1)
+    torch.manual_seed(0)
+    model = DiVAE(Corpus(), cfg).cuda()
+    train_feed, valid_feed = Feed("Train", data[:100], 10), Feed("Valid", data[100:], 10)
+    first = engine.validate(model, valid_feed, cfg)
+    best = engine.train(model, train_feed, valid_feed, valid_feed, cfg)
+    assert best < 0.7 * first, (first, best)
+    ckpt = os.path.join(str(tmp_path), "model")
+    sd = torch.load(ckpt, weights_only=True)
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    model2 = DiVAE(Corpus(), cfg).cuda()
+    model2.load_state_dict(sd)
+    lm = engine.LossManager()
+    lm.add_loss({"nll": torch.tensor(2.0), "flag": True, "none": None})
+    assert "PPL" in lm.pprint("x") and "nll 2.000" in lm.pprint("x", prefix="p")
+
+
+def test_rnn_utt_encoder_vs_reference():
+    from laed_amd.enc2dec.encoders import RnnUttEncoder
+    G = load_golden("modules")
+    for attn in (0, 1):
+        tag = "uttenc_attn%d/" % attn
+        ue = RnnUttEncoder(8, 0.0, bidirection=True, use_attn=bool(attn), vocab_size=17, embed_dim=6)
+        sd = {k[len(tag + "sd/"):]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith(tag + "sd/")}
+        assert sorted(sd.keys()) == sorted(ue.state_dict().keys())
+        ue.load_state_dict(sd)
+        ue.cuda()
+        emb, outs, last, a = ue(torch.from_numpy(G[tag + "utts"]).cuda(), return_all=True)
+        assert rel_err(emb.detach().cpu(), G[tag + "out"]) < 1e-5
+        assert rel_err(outs.detach().cpu(), G[tag + "enc_outs"]) < 1e-5
+        if attn:
+            assert rel_err(a.detach().cpu(), G[tag + "attn"]) < 1e-5
+
+
+def test_encoder_decoder_modules_vs_reference():
+    from laed_amd.enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
+    from laed_amd.enc2dec.encoders import EncoderRNN
+    G = load_golden("modules")
+    for bi in (0, 1):
+        tag = "enc_bi%d/" % bi
+        enc = EncoderRNN(6, 10, bidirection=bool(bi))
+        enc.load_state_dict({k[len(tag + "sd/"):]: torch.from_numpy(np.array(G[k])) for k in G.files
+                             if k.startswith(tag + "sd/")})
+        enc.cuda()
+        x, h0 = torch.from_numpy(G[tag + "x"]).cuda(), torch.from_numpy(G[tag + "h0"]).cuda()
+        out, hid = enc(x)
+        assert rel_err(out.detach().cpu(), G[tag + "out"]) < 1e-5 and rel_err(hid.detach().cpu(), G[tag + "hid"]) < 1e-5
+        out, hid = enc(x, init_state=h0)
+        assert rel_err(out.detach().cpu(), G[tag + "out_h0"]) < 1e-5 and rel_err(hid.detach().cpu(), G[tag + "hid_h0"]) < 1e-5
+    dec = DecoderRNN(13, 6, 5, 9, 2, 3, n_layers=1, rnn_cell='gru', use_gpu=True)
+    dec.load_state_dict({k[len("dec/sd/"):]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith("dec/sd/")})
+    dec.cuda().eval()
+    ids, h0 = torch.from_numpy(G["dec/ids"]).cuda(), torch.from_numpy(G["dec/h0"]).cuda()
+    with torch.no_grad():
+        logp, hid, _ = dec(4, ids, h0, mode=TEACH_FORCE)
+        gout, ghid, ret = dec(4, None, h0, mode=GEN, gen_type='greedy')
+    assert rel_err(logp.materialize().cpu(), G["dec/logp"]) < 1e-5 and rel_err(hid.cpu(), G["dec/hid"]) < 1e-5
+    assert np.array_equal(torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy(), G["dec/gen_seq"])
+    assert ret[DecoderRNN.KEY_LENGTH] == G["dec/gen_len"].tolist()
+    assert rel_err(gout.materialize().cpu(), G["dec/gen_logp"]) < 1e-5 and rel_err(ghid.cpu(), G["dec/gen_hid"]) < 1e-5
