@@ -43,6 +43,22 @@ SHAPES = {
 }
 
 
+TRAFFIC_NOTE = ("profiles/r1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                "(tools/pmc_traffic.py; KiB*1024, FETCH doubled per the gfx950 note), bytes per launch, L3 hits included")
+
+
+def pmc_traffic(variant, same_job):
+    """Per-launch L2<->fabric bytes of `variant` from the committed PMC passes of this same job (S-fixed, 1 GPU);
+    None for any other job (the counters cannot be collected inside a normal run)."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not same_job or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["variants"][variant]["bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 class Corpus(object):
     def __init__(self, V):
         self.vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
@@ -130,7 +146,7 @@ def main():
     from laed_amd._lib import lib
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     from laed_amd.models.sent_models import DiVAE
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         parallel.init()
@@ -142,6 +158,7 @@ def main():
     if GB % world:
         raise SystemExit("global batch %d not divisible by %d GPUs" % (GB, world))
     per = GB // world
+    same_job = args.workload == "S-fixed" and GB == SHAPES["S-fixed"][6] and world == 1   # what the PMC passes ran
 
     torch.manual_seed(0)                                     # identical replicas on every rank
     cfg = make_config(E, H, y, k, T, GB)
@@ -162,7 +179,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -185,7 +202,7 @@ def main():
             lib.laed_prof_enable(0)
             lib.laed_prof_collect(prof_out)
         nll = float(loss.nll.detach())
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([elapsed, nll], device="cuda", dtype=torch.float64)
             tmax = t.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,9 +232,10 @@ def main():
             else:
                 issued, peak = achieved, PEAK_FP32_MFMA_TFLOPS
             roofline = {"bound": "mfma", "kernel": VARIANTS[v], "achieved": round(issued, 2),
+                        "traffic_source": TRAFFIC_NOTE if pmc_traffic(VARIANTS[v], same_job) else None,
                         "peak": peak, "unit": "TFLOP/s", "frac": round(issued / peak, 4),
                         "algorithmic_tflops": round(achieved, 2),
-                        "traffic": None, "launches": int(cnt), "avg_launch_ms": round(ms / cnt, 4),
+                        "traffic": pmc_traffic(VARIANTS[v], same_job), "launches": int(cnt), "avg_launch_ms": round(ms / cnt, 4),
                         "gemm_share_of_step": round(tot_ms / args.steps / ms_per_step, 4),
                         "all_gemm_tflops": round(sum(prof_out[i * 3 + 2] for i in range(7)) / (tot_ms * 1e-3) / 1e12, 2)}
         return {"value": round(tokens_per_step * args.steps / elapsed, 1), "ms_per_step": round(ms_per_step, 3),
@@ -256,7 +274,7 @@ def main():
                                    "sample": "%s shape, %d sequences/step (same step order), 1 warm-up + 2 timed steps"
                                              % (args.workload, args.cpu_sample)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

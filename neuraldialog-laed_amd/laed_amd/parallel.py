@@ -9,6 +9,8 @@ Each rank's loss is then its share of the global loss, so gradients are combined
 launched per parameter from a post-accumulate-grad hook on a side stream: decoder.project.weight (74 % of
 the bytes) is produced first in backward and its reduce overlaps the GRU backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,7 +24,8 @@ def init(group=None):
     if not dist.is_initialized():
         raise RuntimeError("laed_amd.parallel.init: torch.distributed is not initialised")
     _GROUP = group if group is not None else dist.group.WORLD
-    _ENABLED = dist.get_world_size(_GROUP) > 1
+    # LAED_DP_FORCE=1 keeps the DP path (hooks, side stream, collectives) on even for a 1-rank group: rehearsal aid
+    _ENABLED = dist.get_world_size(_GROUP) > 1 or os.environ.get("LAED_DP_FORCE", "0") == "1"
 
 
 def shutdown():
