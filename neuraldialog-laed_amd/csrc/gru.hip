@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void add_parts_kernel(float* __restrict__ y, c
 
 extern "C" int64_t laed_gru_bwd_workspace(int T, int B, int E, int H) {
     const int64_t TBp = ((int64_t)T * B + 31) / 32 * 32;
-    int64_t n = (int64_t)16 * B * H + (int64_t)4 * 3 * H * ((H > E ? H : E) + 1);          // split-K scratch
+    int64_t n = (int64_t)16 * B * H + (int64_t)8 * 3 * H * ((H > E ? H : E) + 1);          // split-K scratch
     if (laed_get_gemm_mode() == 1)
         n += (int64_t)3 * H * H + (int64_t)3 * H * E + (int64_t)3 * H * TBp + (int64_t)H * TBp;   // transposed operands
     return n;

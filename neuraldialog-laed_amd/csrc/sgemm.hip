@@ -429,14 +429,29 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     int S = 1;
     if (a.ws != nullptr && t128 < 512) {
         const int64_t per = (int64_t)a.M * a.N + (a.colsum ? a.M : 0);
-        const int cap = (int)(ws_floats / (per > 0 ? per : 1));
-        int want;
-        if (use_x || (t128 >= 128 && nkt >= 64)) { big = true; want = (int)((512 + t128 - 1) / t128); }
-        else { big = false; want = (int)((512 + t64 - 1) / t64); }
+        const int64_t cap64 = ws_floats / (per > 0 ? per : 1);
+        const int cap = (int)(cap64 < 64 ? cap64 : 64);
         const int by_k = nkt / 8;                         // keep >= 8 K tiles per split
-        S = want < by_k ? want : by_k;
-        if (S > cap) S = cap;
-        if (S > 16) S = 16;
+        if (use_x || (nkt >= 64 && t128 >= 128) || (nkt >= 512 && t128 >= 32)) {
+            // long-K problem on 128x128 tiles: pick the split whose grid fills whole rounds of the 512 resident
+            // block slots (2 per CU); e.g. 192 tiles: S=3 -> 576 blocks = 1.1 rounds (56 % busy), S=8 -> 3.0 rounds.
+            big = true;
+            int smax = by_k < cap ? by_k : cap;
+            if (smax > 32) smax = 32;
+            float best = -1.f;
+            for (int s = 1; s <= smax; ++s) {
+                const int64_t blocks = t128 * s;
+                const int64_t rounds = (blocks + 511) / 512;
+                const float eff = (float)blocks / (float)(rounds * 512) - 0.004f * (float)s;   // reduce cost grows with s
+                if (eff > best + 1e-6f) { best = eff; S = s; }
+            }
+        } else {
+            big = false;
+            const int want = (int)((512 + t64 - 1) / t64);
+            S = want < by_k ? want : by_k;
+            if (S > cap) S = cap;
+            if (S > 16) S = 16;
+        }
         if (S < 1) S = 1;
         if (S == 1) big = use_x || t128 >= 192;
     }
