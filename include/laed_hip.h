@@ -146,6 +146,25 @@ int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t*
                   float* workspace, int64_t ws_floats, int chunk_rows,
                   float* tok_nll, float* lse, float* dh, float* dW, float* db, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Expected embedding of the decoder's output distribution ("attribute forcing" of AE-ED / ST-ED):
+ *   out[N][E] = softmax(h W^T + b) Wemb
+ * Replaces torch.exp(dec_outs.view(-1, V)) @ x_embedding.weight, laed/models/dialog_models.py:421-422
+ * (AeED) and :726-727 (StED), and its autograd backward; the [N][V] probabilities live only in a
+ * [chunk_rows][ldl] workspace tile (two tiles in backward, which recomputes the logits from h).
+ *   fwd: lse[N] (saved for backward), out[N][E]
+ *   bwd: dout[N][E] -> dh[N][H], dW[V][H] (+)=, db[V] (+)=, dWemb[V][E] (+)=   ((+)= if accumulate_w)
+ *   workspace: laed_softmax_embed_workspace(V, chunk_rows, backward) floats
+ * ------------------------------------------------------------------------------------------ */
+int64_t laed_softmax_embed_workspace(int V, int chunk_rows, int backward);
+int laed_softmax_embed_fwd(const float* h, const float* W, const float* b, const float* Wemb,
+                           int64_t N, int H, int V, int E, float* workspace, int64_t ws_floats, int chunk_rows,
+                           float* lse, float* out, void* stream);
+int laed_softmax_embed_bwd(const float* h, const float* W, const float* b, const float* Wemb, const float* lse,
+                           const float* dout, int64_t N, int H, int V, int E,
+                           float* workspace, int64_t ws_floats, int chunk_rows,
+                           float* dh, float* dW, float* db, float* dWemb, int accumulate_w, void* stream);
+
 /* log-probabilities for callers that really want the [N][V] tensor (DecoderRNN's public contract,
  * decoders.py:166): logp = logits - lse, in place on a caller buffer of [N][ldl]. */
 int laed_log_softmax_rows(float* logits, int64_t N, int V, int ldl, float* lse, void* stream);

@@ -43,6 +43,9 @@ _SIGS = {
     "laed_proj_nll_ldl": ([_i], _i),
     "laed_proj_nll_workspace": ([_i, _i, _i], _i64),
     "laed_proj_nll": ([_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _i, _p, _i64, _i, _p, _p, _p, _p, _p, _p], _i),
+    "laed_softmax_embed_workspace": ([_i, _i, _i], _i64),
+    "laed_softmax_embed_fwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _p, _i64, _i, _p, _p, _p], _i),
+    "laed_softmax_embed_bwd": ([_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _i64, _i, _p, _p, _p, _p, _i, _p], _i),
     "laed_log_softmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_argmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_nll_reduce": ([_p, _p, _i64, _i64, _p, _p], _i),

@@ -39,6 +39,14 @@ class LazyLogProbs(object):
                 self._dense = buf[:, :self.V].view(self.B, self.T, self.V)
         return self._dense
 
+    def expected_embedding_tm(self, emb_weight):
+        """softmax(project(h)) @ emb_weight as a time-major [T,B,E] tensor, differentiable w.r.t. h, the projection and
+        the embedding table, without forming the probabilities (= exp(log-probs) @ weight, dialog_models.py:421-423)."""
+        T, B = self.T, self.B
+        out = ops.SoftmaxEmbedFunction.apply(self.h_tm.reshape(T * B, -1), self.project.weight, self.project.bias,
+                                             emb_weight)
+        return out.view(T, B, -1)
+
     def size(self, *a):
         return torch.Size((self.B, self.T, self.V)) if not a else (self.B, self.T, self.V)[a[0]]
 

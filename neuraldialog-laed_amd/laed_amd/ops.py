@@ -367,6 +367,45 @@ class ProjNLLFunction(torch.autograd.Function):
         return dh, dW, db, None, None, None
 
 
+class SoftmaxEmbedFunction(torch.autograd.Function):
+    """h[N,H], W[V,H], b[V], Wemb[V,E] -> softmax(h W^T + b) Wemb  [N,E]; the [N,V] probabilities only ever exist
+    as workspace tiles (dialog_models.py:421-422 'attribute forcing').  Backward recomputes the logits per chunk."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, Wemb):
+        h = _f32c(h)
+        N, H = h.shape
+        V, E = Wemb.shape
+        dev = h.device
+        chunk = proj_chunk_rows(N, V, H)
+        ws_n = int(lib.laed_softmax_embed_workspace(int(V), int(chunk), 0))
+        ws = workspace("proj", ws_n, dev)
+        lse = torch.empty(N, device=dev, dtype=torch.float32)
+        out = torch.empty((N, E), device=dev, dtype=torch.float32)
+        check(lib.laed_softmax_embed_fwd(ptr(h), ptr(W), ptr(b), ptr(Wemb), N, H, V, E, ptr(ws), ws_n, int(chunk),
+                                         ptr(lse), ptr(out), stream()), "laed_softmax_embed_fwd")
+        ctx.save_for_backward(h, W, b, Wemb, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, W, b, Wemb, lse = ctx.saved_tensors
+        N, H = h.shape
+        V, E = Wemb.shape
+        dev = h.device
+        chunk = max(128, proj_chunk_rows(N, V, H) // 2) if N > 128 else proj_chunk_rows(N, V, H)   # two tiles
+        ws_n = int(lib.laed_softmax_embed_workspace(int(V), int(chunk), 1))
+        ws = workspace("proj", ws_n, dev)
+        dh = torch.empty_like(h)
+        dW = torch.empty_like(W)
+        db = torch.empty(V, device=dev, dtype=torch.float32)
+        dWemb = torch.empty_like(Wemb)
+        check(lib.laed_softmax_embed_bwd(ptr(h), ptr(W), ptr(b), ptr(Wemb), ptr(lse), ptr(_f32c(dout)), N, H, V, E,
+                                         ptr(ws), ws_n, int(chunk), ptr(dh), ptr(dW), ptr(db), ptr(dWemb), 0, stream()),
+              "laed_softmax_embed_bwd")
+        return dh, dW, db, dWemb
+
+
 class LogSoftmaxKFunction(torch.autograd.Function):
     """log_softmax over the last (k <= 64) dimension of a [R,k] matrix: the posterior log q(y|x)."""
 

@@ -112,3 +112,33 @@ def test_greedy_connector():
     logits = torch.tensor([[0.1, 2.0, 2.0], [3.0, -1.0, 0.0]])
     y, ids = GreedyConnector()(logits, False, return_max_id=True)
     assert ids.view(-1).tolist() == [1, 0] and y.tolist() == [[0, 1, 0], [1, 0, 0]]
+
+
+def test_dialog_models_state_dict_and_freeze_switch():
+    """AE-ED / ST-ED: reference state_dict keys/shapes, shared embedding tables, and the freeze_step phase switch of
+    valid_loss (dialog_models.py:278-307, :549-585) -- host logic only, no kernel launches."""
+    from laed_amd.models.dialog_models import AeED, StED
+    from laed_amd.utils import Pack
+    for name, cls in (("aeed_tiny", AeED), ("sted_tiny", StED)):
+        G = load_golden(name)
+        cfg = golden_config(G)
+        model = cls(Corpus(int(G["config/vocab_size"])), cfg)
+        assert list(model.state_dict().keys()) == [str(k) for k in G["meta/state_dict_keys"]]
+        for k, v in model.state_dict().items():
+            assert tuple(v.shape) == G["sd/" + k].shape, k
+        assert model.decoder.embedding.weight is model.embedding.weight
+        assert model.utt_encoder.embedding.weight is model.embedding.weight
+        assert model.x_embedding.padding_idx is None and float(model.x_embedding.weight[0].abs().sum()) > 0.0
+        one = torch.ones(())
+        loss = Pack(nll=one * 2, pi_kl=one * 3, pi_nll=one * 5, attribute_nll=one * 10, vae_nll=one * 7,
+                    vst_prev_nll=one * 7, vst_next_nll=one * 11, reg_kl=one * 13, mi=one, pi_err=one * 0.25,
+                    adv_err=one * 0.5)
+        phase_a = 7 + 13 if cls is AeED else 7 + 11 + 13
+        phase_b = 2 + 5 + (1.0 if cls is AeED else 10.0)
+        assert float(model.valid_loss(loss, 0)) == phase_a and model.kl_w == 0.0 and not model.flush_valid
+        assert float(model.model_sel_loss(loss, 0)) == phase_a
+        assert float(model.valid_loss(loss, cfg.freeze_step + 1)) == phase_b
+        assert model.kl_w == 1.0 and model.flush_valid
+        assert [int(p.requires_grad) for _, p in model.named_parameters()] == [int(r) for r in G["flip/requires_grad"]]
+        assert float(model.model_sel_loss(loss, cfg.freeze_step + 1)) == 0.75
+        assert float(loss.nll) == 2.0          # valid_loss is out of place here (the reference mutates loss.nll)
