@@ -111,3 +111,71 @@ def test_encoder_decoder_modules_vs_reference():
     assert np.array_equal(torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy(), G["dec/gen_seq"])
     assert ret[DecoderRNN.KEY_LENGTH] == G["dec/gen_len"].tolist()
     assert rel_err(gout.materialize().cpu(), G["dec/gen_logp"]) < 1e-5 and rel_err(ghid.cpu(), G["dec/gen_hid"]) < 1e-5
+
+
+def _toy_dialogs(rs, n, V, T):
+    """Dialogs whose turns are arithmetic token runs (next token = previous + 1), so the models have something to learn."""
+    from laed_amd.utils import Pack
+    dialogs = []
+    for _ in range(n):
+        turns = [Pack(utt=[2, 4, 3], speaker=0, meta=None)]
+        start = int(rs.randint(4, V))
+        for t in range(int(rs.randint(4, 7))):
+            L = int(rs.randint(4, T - 1))
+            body = [(start + t + j - 4) % (V - 4) + 4 for j in range(L)]
+            turns.append(Pack(utt=[2] + body + [3], speaker=t % 2, meta=None))
+        dialogs.append(turns)
+    return dialogs
+
+
+def test_loaders_engine_and_dialog_models_end_to_end(tmp_path):
+    """data_loaders -> engine.train -> AE-ED through its freeze_step switch (optimizer re-created on flush_valid),
+    and DI-VST on the skip loader: validation loss improves, checkpoints carry the reference's keys."""
+    from laed_amd import main as engine
+    from laed_amd.dataset import data_loaders
+    from laed_amd.models.dialog_models import AeED
+    from laed_amd.models.sent_models import DiVST
+    V, T = 40, 10
+    rs = np.random.RandomState(1)
+
+    class Corpus(object):
+        vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
+        rev_vocab = {w: i for i, w in enumerate(vocab)}
+
+    base = dict(embed_size=16, max_utt_len=T, num_layer=1, dropout=0.1, dec_cell_size=32, rnn_cell='gru', max_dec_len=T,
+                use_attn=False, beam_size=4, attn_type='cat', fix_batch=False, y_size=3, k=5, use_gpu=True,
+                avg_type='word', use_reg_kl=True, init_lr=0.01, op='adam', print_step=20, ckpt_step=30, max_epoch=3,
+                early_stop=False, improve_threshold=0.996, patient_increase=2.0, save_model=True,
+                preview_batch_num=1, batch_size=8, backward_size=3)
+
+    # ---- AE-ED: 90 steps, recognition side frozen after step 40
+    cfg = Namespace(utt_type='attn_rnn', utt_cell_size=8, ctx_cell_size=32, use_attribute=True, greedy_q=True,
+                    freeze_step=40, session_dir=str(tmp_path / "ae"), **base)
+    os.makedirs(cfg.session_dir)
+    torch.manual_seed(0)
+    model = AeED(Corpus(), cfg).cuda()
+    train_feed = data_loaders.SMDDataLoader("Train", _toy_dialogs(rs, 60, V, T), cfg)
+    valid_feed = data_loaders.SMDDataLoader("Valid", _toy_dialogs(rs, 12, V, T), cfg)
+    first = engine.validate(model, valid_feed, cfg, 0)
+    engine.train(model, train_feed, valid_feed, valid_feed, cfg)
+    assert model.kl_w == 1.0 and not model.flush_valid
+    assert not any(p.requires_grad for p in model.x_decoder.parameters())
+    assert all(p.requires_grad for p in model.decoder.parameters())
+    model.eval()
+    valid_feed.epoch_init(cfg, shuffle=False, verbose=False)
+    with torch.no_grad():
+        loss = model(valid_feed.next_batch(), mode="teacher_forcing")
+    assert float(loss.nll) < 0.8 * first and float(loss.vae_nll) < 0.8 * first, (first, float(loss.nll))
+    sd = torch.load(os.path.join(cfg.session_dir, "model"), weights_only=True)
+    assert list(sd.keys()) == list(model.state_dict().keys())
+
+    # ---- DI-VST on the skip loader
+    cfg = Namespace(enc_cell_size=32, utt_type='rnn', bi_enc_cell=False, use_mutual=True, train_prior=False,
+                    session_dir=str(tmp_path / "vst"), **base)
+    os.makedirs(cfg.session_dir)
+    model = DiVST(Corpus(), cfg).cuda()
+    train_feed = data_loaders.DailyDialogSkipLoader("Train", _toy_dialogs(rs, 60, V, T), cfg)
+    valid_feed = data_loaders.DailyDialogSkipLoader("Valid", _toy_dialogs(rs, 12, V, T), cfg)
+    first = engine.validate(model, valid_feed, cfg, 0)
+    best = engine.train(model, train_feed, valid_feed, valid_feed, cfg)
+    assert best < 0.8 * first, (first, best)
