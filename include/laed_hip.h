@@ -181,6 +181,16 @@ int laed_gru_decode_greedy(const float* emb, const float* w_ih, const float* w_h
                            int B, int E, int H, int V, int max_len, int64_t go_id,
                            float* hbuf, float* xbuf, float* gates, float* logits, int64_t* ids_out, void* stream);
 
+/* Sampled free-running decode, gen_type='sample' (decoders.py:220-221 -> gumbel_max, base_modules.py:54-67):
+ * as laed_gru_decode_greedy but step t picks argmax_v (log_softmax(logits)[v] - log(-log(u[t][r][v]))).
+ * u: [max_len][B][V] uniforms to replay, or NULL = the library's counter RNG keyed by (seed, t, row0 + r, v)
+ * (row0 = global row of this rank's first row, so a sharded job draws the single-GPU job's noise). */
+int laed_gru_decode_sample(const float* emb, const float* w_ih, const float* w_hh, const float* b_ih,
+                           const float* b_hh, const float* proj_w, const float* proj_b, const float* h0,
+                           int B, int E, int H, int V, int max_len, int64_t go_id,
+                           const float* u, uint64_t seed, uint64_t row0,
+                           float* hbuf, float* xbuf, float* gates, float* logits, int64_t* ids_out, void* stream);
+
 /* masked reductions used by NLLEntropy's averaging modes (criterions.py:47-68):
  * out[0] = sum_r tok_nll[r], out[1] = #(labels != pad). */
 int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int64_t N, int64_t pad_id, float* out, void* stream);

@@ -83,6 +83,10 @@ class DecoderRNN(BaseRNN):
         self.drop_seed = 4321
         self.drop_step = 0
         self.injected_keep = None          # tests: keep mask [B,T,E] (1 keep / 0 drop), used instead of the RNG
+        # noise control for gen_type='sample' (gumbel_max, base_modules.py:54-67)
+        self.sample_seed = 9876
+        self.sample_step = 0
+        self.injected_u = None             # tests: uniforms [max_len,B,V] replayed instead of the RNG
 
     def _keep_mask_tm(self, B, T, device):
         """uint8 keep mask in time-major layout [T,B,E]; RNG keyed by the GLOBAL batch row."""
@@ -119,15 +123,23 @@ class DecoderRNN(BaseRNN):
             ret_dict[DecoderRNN.KEY_SEQUENCE] = []
             ret_dict[DecoderRNN.KEY_LENGTH] = [self.max_length] * batch_size
             return decoder_outputs, decoder_hidden, ret_dict
-        if gen_type != 'greedy':
-            raise NotImplementedError("gen_type '%s': only greedy decoding is on the hot path (sample/beam are "
-                                      "listed as next in SURVEY.md section 8f)" % gen_type)
+        if gen_type not in ('greedy', 'sample'):
+            raise NotImplementedError("gen_type '%s': greedy and sample decoding are built; beam search does not run in "
+                                      "the reference under Python 3 either (decoders.py:289)" % gen_type)
         with torch.no_grad():
             h0 = init_state[0].detach().contiguous()
+            sample = gen_type == 'sample'
+            u = None
+            if sample and self.injected_u is not None:          # tests: replay recorded uniforms [max_len,B,V]
+                u = torch.as_tensor(self.injected_u, dtype=torch.float32).to(h0.device).contiguous()
             ids, hbuf = ops.decode_greedy(self.embedding.weight.detach(), self.rnn.weight_ih_l0.detach(),
                                           self.rnn.weight_hh_l0.detach(), self.rnn.bias_ih_l0.detach(),
                                           self.rnn.bias_hh_l0.detach(), self.project.weight.detach(),
-                                          self.project.bias.detach(), h0, self.max_length, self.sos_id)
+                                          self.project.bias.detach(), h0, self.max_length, self.sos_id,
+                                          sample=sample, u=u, seed=(self.sample_seed * 1000003 + self.sample_step),
+                                          row0=parallel.rank() * batch_size)
+            if sample:
+                self.sample_step += 1
         # ids [L,B]; EOS bookkeeping as decoders.py:241-245 (first EOS position + 1, else max_length)
         ids_bf = ids.t().contiguous()
         host = ids_bf.cpu().numpy()

@@ -6,9 +6,9 @@ forward / valid_loss / model_sel_loss semantics and Pack keys as the reference. 
 kernels as DI-VAE / DI-VST; the one new kernel is the attribute-forcing head, which needs
 softmax(dec_outs) @ x_embedding.weight and gets it from laed_softmax_embed_{fwd,bwd} without forming [N,V].
 
-Limits (raise NotImplementedError): decoder attention (use_attn), LSTM cells, fix_batch, 'sample' / beam decoding
-(min_forward), data parallelism for these two models.  valid_loss sums out of place (the reference's AeED mutates
-loss.nll in place, dialog_models.py:280-284).
+Limits (raise NotImplementedError): decoder attention (use_attn), LSTM cells, fix_batch, beam decoding, data
+parallelism for these two models.  valid_loss sums out of place (the reference's AeED mutates loss.nll in place,
+dialog_models.py:280-284).
 """
 import itertools
 
@@ -207,7 +207,23 @@ class LAED(BaseModel):
         return Pack(nll=torch.sum(nll_xcz) / all_words)
 
     def min_forward(self, data_feed, batch_size, sample_n):
-        raise NotImplementedError("min_forward decodes with gen_type='sample', which is not built (SURVEY.md 8f rank 4)")
+        """sample_n prior samples per context, each decoded with gen_type='sample' (dialog_models.py:145-182)."""
+        ctx_lens = data_feed['context_lens']
+        ctx_utts = self.np2var(data_feed['contexts'], LONG)
+        _, c_last, py_logits, log_py = self._context_prior(ctx_utts, ctx_lens)
+        ys, ids = [], []
+        for _ in range(sample_n):
+            t_y, t_id = self.cat_connector(py_logits, 1.0, self.use_gpu, hard=True, return_max_id=True)
+            ids.append(t_id.view(-1, self.config.y_size))
+            ys.append(t_y.view(-1, self.config.k * self.config.y_size))
+        sample_y, y_id = torch.cat(ys, dim=0), torch.cat(ids, dim=0)
+        batch_size *= sample_n
+        dec_init_state = self.c_init_connector(sample_y) + c_last.repeat(sample_n, 1).unsqueeze(0)
+        _, _, dec_ctx = self.decoder(batch_size, None, dec_init_state, attn_context=None, mode=GEN, gen_type="sample",
+                                     beam_size=self.config.beam_size)
+        dec_ctx[DecoderRNN.KEY_LATENT] = y_id
+        dec_ctx[DecoderRNN.KEY_POLICY] = log_py
+        return dec_ctx
 
 
 class AeED(LAED):

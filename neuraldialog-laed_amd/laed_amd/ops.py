@@ -151,7 +151,10 @@ def log_softmax_rows_(buf, V):
     return buf
 
 
-def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_id):
+def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_id, sample=False, u=None, seed=0,
+                  row0=0):
+    """Free-running decode from h0 [B,H]: greedy, or (sample=True) Gumbel-max sampling with replayed uniforms
+    u [max_len,B,V] or the counter RNG keyed by (seed, step, row0 + row)."""
     B, H = h0.shape
     V, E = emb.shape
     dev = h0.device
@@ -160,6 +163,14 @@ def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_i
     gates = torch.empty((B, 3 * H), device=dev, dtype=torch.float32)
     logits = torch.empty((B, proj_ldl(V)), device=dev, dtype=torch.float32)
     ids = torch.empty((max_len + 1, B), device=dev, dtype=I64)
+    if sample:
+        if u is not None and tuple(u.shape) != (max_len, B, V):
+            raise ValueError("decode: u must be [max_len, B, V] = %s, got %s" % ((max_len, B, V), tuple(u.shape)))
+        check(lib.laed_gru_decode_sample(ptr(emb), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(proj_w), ptr(proj_b),
+                                         ptr(h0), B, E, H, V, int(max_len), int(go_id), ptr(u), int(seed), int(row0),
+                                         ptr(hbuf), ptr(xbuf), ptr(gates), ptr(logits), ptr(ids, I64), stream()),
+              "laed_gru_decode_sample")
+        return ids[1:], hbuf
     check(lib.laed_gru_decode_greedy(ptr(emb), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(proj_w), ptr(proj_b),
                                      ptr(h0), B, E, H, V, int(max_len), int(go_id), ptr(hbuf), ptr(xbuf), ptr(gates),
                                      ptr(logits), ptr(ids, I64), stream()), "laed_gru_decode_greedy")

@@ -157,6 +157,25 @@ def decoder_greedy(P, prefix, emb_w, h0, max_len, go_id, eos_id):
     return torch.cat(seq, dim=1), lengths.tolist(), torch.cat(lps, dim=1)
 
 
+def decoder_sample(P, prefix, emb_w, h0, max_len, go_id, eos_id, u):
+    """DecoderRNN GEN with gen_type='sample': decoders.py:220-221 -> gumbel_max, base_modules.py:54-67
+    (symbols = argmax(log_probs - log(-log(u)))), u [max_len,B,V] replayed uniforms.  Same bookkeeping as greedy."""
+    B = h0.shape[0]
+    ids = torch.full((B, 1), go_id, dtype=torch.int64)
+    h = h0
+    seq = []
+    lengths = np.array([max_len] * B)
+    for di in range(max_len):
+        lp, h = decoder_teacher(P, prefix, emb_w, ids, h)
+        g = -1.0 * torch.log(-1.0 * torch.log(torch.as_tensor(u[di])))
+        ids = torch.max(lp[:, 0] + g, dim=-1, keepdim=True)[1]
+        seq.append(ids)
+        eos = (ids.view(-1) == eos_id).numpy()
+        upd = (lengths > di) & eos
+        lengths[upd] = len(seq)
+    return torch.cat(seq, dim=1), lengths.tolist(), h
+
+
 # --------------------------------------------------------------------------------------
 # models (functional; P = dict name -> tensor with the reference's state_dict keys)
 # --------------------------------------------------------------------------------------

@@ -179,3 +179,31 @@ def test_loaders_engine_and_dialog_models_end_to_end(tmp_path):
     first = engine.validate(model, valid_feed, cfg, 0)
     best = engine.train(model, train_feed, valid_feed, valid_feed, cfg)
     assert best < 0.8 * first, (first, best)
+
+
+def test_sample_decoding_vs_reference():
+    """gen_type='sample' through laed_gru_decode_sample with the golden's replayed uniforms: ids exact; and with the
+    library RNG: reproducible for a fixed (seed, step), different across steps, every id in range."""
+    from laed_amd.enc2dec.decoders import GEN, DecoderRNN
+    G = load_golden("sample")
+    L, B, V = G["u"].shape
+    dec = DecoderRNN(V, L, 6, 12, 2, 3, n_layers=1, rnn_cell='gru')
+    dec.load_state_dict({k[3:]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith("sd/")})
+    dec.cuda().eval()
+    h0 = torch.from_numpy(G["h0"]).cuda()
+    dec.injected_u = G["u"]
+    outs, hid, ret = dec(B, None, h0, mode=GEN, gen_type='sample')
+    seq = torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy()
+    assert np.array_equal(seq, G["sequence"])
+    assert list(ret[DecoderRNN.KEY_LENGTH]) == list(G["length"])
+    assert rel_err(hid.cpu(), G["hid"]) < 1e-5
+    dec.injected_u = None
+    runs = []
+    for step in (0, 0, 1):
+        dec.sample_step = step
+        _, _, ret = dec(B, None, h0, mode=GEN, gen_type='sample')
+        runs.append(torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy())
+    assert np.array_equal(runs[0], runs[1]) and not np.array_equal(runs[0], runs[2])
+    assert runs[2].min() >= 0 and runs[2].max() < V
+    with pytest.raises(NotImplementedError):
+        dec(B, None, h0, mode=GEN, gen_type='beam')

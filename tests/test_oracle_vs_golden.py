@@ -192,3 +192,17 @@ def test_module_form_matches_functional():
     res = model(G["in/outputs"], G["in/u_steps"][0])
     for k in ("nll", "reg_kl", "mi", "bpr"):
         assert abs(float(res[k]) - float(G["out/" + k])) <= 1e-6 + 1e-5 * abs(float(G["out/" + k])), k
+
+
+def test_sample_decoding_gumbel_max():
+    """gen_type='sample' (tests/golden/make_goldens_sample.py: the reference decoder with a replayed uniform stream)."""
+    G = load_golden("sample")
+    P = {"dec." + k[3:]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith("sd/")}
+    assert float(G["margin"].min()) > 1e-3
+    L = G["u"].shape[0]
+    with torch.no_grad():
+        seq, lengths, hT = O.decoder_sample(P, "dec.", P["dec.embedding.weight"], torch.from_numpy(G["h0"][0]), L, 2, 3,
+                                            G["u"])
+    assert np.array_equal(seq.numpy(), G["sequence"])
+    assert list(lengths) == list(G["length"])
+    assert rel_err(hT, G["hid"][0]) < 2e-6
