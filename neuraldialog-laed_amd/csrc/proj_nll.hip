@@ -229,12 +229,17 @@ inline int rows_grid(int64_t rows) { return (int)(rows < 4096 ? (rows < 1 ? 1 : 
 
 }   // namespace
 
+// dh = dl W has only (rows/128) x (H/128) output tiles but K = V is long: chunks that do not fill whole rounds of the
+// chip's 512 resident blocks (the last chunk, or every chunk of a small per-GPU batch) split K up to this many ways.
+constexpr int DH_SPLITS = 8;
+
 extern "C" int laed_proj_nll_ldl(int V) { return (V + 31) / 32 * 32; }
 
 // floats of workspace laed_proj_nll needs for the current GEMM math mode
 extern "C" int64_t laed_proj_nll_workspace(int H, int V, int chunk_rows) {
     const int64_t ldl = laed_proj_nll_ldl(V);
     int64_t n = (int64_t)chunk_rows * ldl;
+    n += (int64_t)DH_SPLITS * chunk_rows * H;          // split-K partials of the dh GEMM (short chunks, long K = V)
     if (laed_get_gemm_mode() == 1) {
         const int64_t ldr = (chunk_rows + 31) / 32 * 32;
         n += (int64_t)V * ldr + (int64_t)H * ldr + (int64_t)H * ldl;   // dl^T, h^T, W^T (K-contiguous operands)
@@ -259,7 +264,9 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
     // split-bf16 mode: every product is brought to the K-contiguous (x W^T) form via fp32 transposed copies
     const bool xmode = laed_get_gemm_mode() == 1 && with_grad;
     const int64_t ldr = (chunk_rows + 31) / 32 * 32;
-    float* dlT = workspace + (int64_t)chunk_rows * ldl;   // [V][ldr]
+    float* dh_ws = workspace + (int64_t)chunk_rows * ldl;          // [DH_SPLITS][chunk_rows][H] split-K partials
+    const int64_t dh_ws_floats = (int64_t)DH_SPLITS * chunk_rows * H;
+    float* dlT = dh_ws + dh_ws_floats;                             // [V][ldr]
     float* hT = dlT + (int64_t)V * ldr;                    // [H][ldr]
     float* WT = hT + (int64_t)H * ldr;                     // [H][ldl]
     if (xmode) LAED_TRY(laed_transpose_impl(W, H, V, H, WT, ldl, stream));
@@ -283,7 +290,8 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
             LAED_TRY(laed_sgemm_rowsum_impl(V, H, rows, dlT, ldr, hT, ldr, dW, H, acc, db, acc, nullptr, 0, stream));
             acc = true;
         } else if (with_grad) {
-            LAED_TRY(laed_sgemm_impl(false, false, rows, H, V, workspace, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
+            LAED_TRY(laed_sgemm_splitk_impl(false, false, rows, H, V, workspace, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr,
+                                            false, dh_ws, dh_ws_floats, false, nullptr, stream));
             LAED_TRY(laed_sgemm_impl(true, false, V, H, rows, workspace, ldl, hc, H, dW, H, nullptr, acc, db, acc, stream));
             acc = true;
         }

@@ -232,18 +232,32 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     __syncthreads();
 
     int cur = 0, kt = 0;
-    if (fast) {
-        // ---- scheduled loop: tile kt computes while full tile kt+1 is fetched and staged
+    if (fast && nfull >= 2) {
+        // ---- scheduled loop, prefetch distance = one whole K tile: while tile kt computes out of LDS[cur], the
+        // registers (tile kt+1, fetched during tile kt-1) are written to LDS[cur^1] and immediately refilled with
+        // tile kt+2, unit by unit.  A global load therefore has a full tile of MFMA time (>= 4096 cycles per wave)
+        // to land before its s_waitcnt, which covers an HBM miss under load; with the half-tile distance this loop
+        // used before, every K tile stalled on vmcnt in its middle.  The last pass has no tile kt+2 to fetch and
+        // re-reads tile kt+1 (cache hit, result unused) instead of branching.
+        ga += a_step;
+        gb += b_step;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) load_unit(u);
         for (; kt + 1 < nfull; ++kt) {
             const float* a_s = a_base + cur * BK * SA;
             const float* b_s = b_base + cur * BK * SB;
-            ga += a_step;
-            gb += b_step;
-            float af[2][TM], bf[2][TN];
+            if (kt + 2 < nfull) { ga += a_step; gb += b_step; }
+            // fragments are read TWO k pairs ahead (three register sets): the wait before a k pair's first MFMA then
+            // covers reads issued a whole k pair (>= 256 cycles) earlier and leaves the newest reads in flight
+            // (counted lgkmcnt), which is what one or two waves per SIMD need to keep the LDS latency off the MFMA chain
+            float af[3][TM], bf[3][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = a_s[i * 32];
+            for (int s_ = 0; s_ < 2; ++s_) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = b_s[j * 32];
+                for (int i = 0; i < TM; ++i) af[s_][i] = a_s[(2 * s_) * SA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[s_][j] = b_s[(2 * s_) * SB + j * 32];
+            }
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
@@ -251,20 +265,21 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int q_ = kk * NMF + i * TN + j;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-                        if (i * TN + j == 0 && kk + 1 < BK / 2) {        // fragments of the next k pair
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk % 3][i], bf[kk % 3][j], acc[i][j], 0, 0, 0);
+                        if (i * TN + j == 0 && kk + 2 < BK / 2) {        // fragments of the k pair after the next
 #pragma unroll
-                            for (int ii = 0; ii < TM; ++ii) af[(kk + 1) & 1][ii] = a_s[(2 * (kk + 1)) * SA + ii * 32];
+                            for (int ii = 0; ii < TM; ++ii) af[(kk + 2) % 3][ii] = a_s[(2 * (kk + 2)) * SA + ii * 32];
 #pragma unroll
-                            for (int jj = 0; jj < TN; ++jj) bf[(kk + 1) & 1][jj] = b_s[(2 * (kk + 1)) * SB + jj * 32];
+                            for (int jj = 0; jj < TN; ++jj) bf[(kk + 2) % 3][jj] = b_s[(2 * (kk + 2)) * SB + jj * 32];
                         }
 #pragma unroll
                         for (int u = 0; u < NL; ++u) {
-                            if (q_ == (u * (Q / 4)) / NL) load_unit(u);                  // first quarter: HBM loads
-                            if (q_ == Q / 2 + (u * (Q / 4)) / NL) {                      // third quarter: LDS stores
+                            const int gs = Q / 8 + (u * (3 * Q / 4)) / NL;               // store gap of unit u
+                            if (q_ == gs) {
                                 if (u == 0) add_colsum();
-                                store_unit(u, cur ^ 1);
+                                store_unit(u, cur ^ 1);                                  // tile kt+1 -> LDS
                             }
+                            if (q_ == gs + 1) load_unit(u);                              // tile kt+2 -> registers
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
