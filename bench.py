@@ -40,6 +40,8 @@ SHAPES = {
     # name: (V, E, H, y, k, T, global batch)
     "S-fixed": (50000, 200, 1024, 20, 10, 40, 4096),      # BASELINE.json configs[4] (headline)
     "P-fixed": (10002, 200, 512, 20, 10, 40, 30),         # ptb-utt.py defaults (configs[0] shape)
+    "P-varlen": (10002, 200, 512, 20, 10, 40, 30),        # same, lengths ~ clip(round(lognormal(3.0, 0.45)), 3, 40)
+    "VST-fixed": (10004, 200, 512, 20, 10, 40, 60),       # dailydialog-utt-skip.py defaults (configs[1] shape), DI-VST
 }
 
 
@@ -85,11 +87,26 @@ def synth_batch(V, T, B, seed=1234):
     return out
 
 
-def flops_per_step(V, E, H, y, k, T, B):
+def synth_varlen(V, T, B, seed=1234):
+    """P-varlen: len ~ clip(round(lognormal(3.0, 0.45)), 3, T), zero-padded to the batch maximum."""
+    rs = np.random.RandomState(seed)
+    lens = np.clip(np.round(rs.lognormal(3.0, 0.45, size=B)), 3, T).astype(np.int64)
+    out = np.zeros((B, int(lens.max())), dtype=np.int32)
+    for b, L in enumerate(lens):
+        out[b, 0] = 2
+        out[b, 1:L - 1] = rs.randint(4, V, size=L - 2)
+        out[b, L - 1] = 3
+    return out, lens
+
+
+def flops_per_step(V, E, H, y, k, T, B, dec_positions=None):
+    """train step = 3 x forward; dec_positions = decoder input positions per sequence (T-1 for DI-VAE,
+    (Tp-1)+(Tn-1) for DI-VST)."""
     f_enc = 2.0 * 3 * H * (E + H)
     f_dec = 2.0 * 3 * H * (E + H) + 2.0 * H * V
     f_seq = 2.0 * H * y * k + 2.0 * y * k * H
-    return 3.0 * (B * T * f_enc + B * (T - 1) * f_dec + B * f_seq)
+    dp = (T - 1) if dec_positions is None else dec_positions
+    return 3.0 * (B * T * f_enc + B * dp * f_dec + B * f_seq)
 
 
 def cpu_baseline(V, E, H, y, k, T, sample_b, steps=2):
@@ -145,7 +162,7 @@ def main():
     from laed_amd import parallel
     from laed_amd._lib import lib
     from laed_amd.enc2dec.decoders import TEACH_FORCE
-    from laed_amd.models.sent_models import DiVAE
+    from laed_amd.models.sent_models import DiVAE, DiVST
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -162,13 +179,26 @@ def main():
 
     torch.manual_seed(0)                                     # identical replicas on every rank
     cfg = make_config(E, H, y, k, T, GB)
-    model = DiVAE(Corpus(V), cfg).cuda()
+    is_vst = args.workload == "VST-fixed"
+    model = (DiVST if is_vst else DiVAE)(Corpus(V), cfg).cuda()
     model.train()
     opt = model.get_optimizer(cfg)
-    full = synth_batch(V, T, GB)
-    shard = torch.from_numpy(full[rank * per:(rank + 1) * per].astype(np.int64)).cuda()   # inputs resident in HBM
-    feed = {"outputs": shard, "output_lens": [T] * per}
-    tokens_per_step = GB * (T - 1)
+
+    def resident(a):                                         # this rank's rows, resident in HBM before timing
+        return torch.from_numpy(a[rank * per:(rank + 1) * per].astype(np.int64)).cuda()
+    if args.workload == "P-varlen":
+        full, lens = synth_varlen(V, T, GB)
+        T = full.shape[1]
+        tokens_per_step = int((lens - 1).sum())              # non-PAD decoder targets
+        enc_tokens_per_step = GB * T                         # the encoder consumes PAD positions too
+    else:
+        full = synth_batch(V, T, GB)
+        tokens_per_step = GB * (T - 1) * (2 if is_vst else 1)
+        enc_tokens_per_step = GB * T
+    feed = {"outputs": resident(full), "output_lens": [T] * per}
+    if is_vst:
+        feed["prevs"], feed["nexts"] = resident(synth_batch(V, T, GB, seed=1235)), resident(synth_batch(V, T, GB, seed=1236))
+    step_flops = flops_per_step(V, E, H, y, k, T, GB, dec_positions=2 * (T - 1) if is_vst else None)
 
     def step():
         opt.zero_grad()
@@ -192,16 +222,20 @@ def main():
         prof = not args.no_prof
         if prof:
             lib.laed_prof_enable(1)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             loss = step()
+            marks[i + 1].record()                           # device-side per-step spread (no host sync inside the loop)
         fence()
         elapsed = time.perf_counter() - t0
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         prof_out = (ctypes.c_double * 21)()
         if prof:
             lib.laed_prof_enable(0)
             lib.laed_prof_collect(prof_out)
-        nll = float(loss.nll.detach())
+        nll = float((loss.prev_nll + loss.next_nll).detach()) if is_vst else float(loss.nll.detach())
         if dist.is_initialized():
             t = torch.tensor([elapsed, nll], device="cuda", dtype=torch.float64)
             tmax = t.clone()
@@ -240,7 +274,11 @@ def main():
                         "all_gemm_tflops": round(sum(prof_out[i * 3 + 2] for i in range(7)) / (tot_ms * 1e-3) / 1e12, 2)}
         return {"value": round(tokens_per_step * args.steps / elapsed, 1), "ms_per_step": round(ms_per_step, 3),
                 "fwd_bwd_ms": round(fwd_bwd_ms, 3),
-                "step_tflops": round(flops_per_step(V, E, H, y, k, T, GB) / (ms_per_step * 1e-3) / 1e12, 2),
+                "step_ms_device": {"median": round(per_step[len(per_step) // 2], 3),
+                                   "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
+                                   "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3)},
+                "encoder_tokens_per_s": round(enc_tokens_per_step * args.steps / elapsed, 1),
+                "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
                 "final_nll": round(nll, 5), "roofline": roofline}
 
     main_res = measure(args.gemm_mode)
@@ -249,9 +287,11 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train tokens/sec (DI-VAE, whole node)", "value": main_res["value"], "unit": "tokens/s",
+            "metric": "train tokens/sec (%s, whole node)" % ("DI-VST" if is_vst else "DI-VAE"),
+            "value": main_res["value"], "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
-            "fwd_bwd_ms": main_res["fwd_bwd_ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "fwd_bwd_ms": main_res["fwd_bwd_ms"], "step_ms_device": main_res["step_ms_device"],
+            "encoder_tokens_per_s": main_res["encoder_tokens_per_s"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == "fp32" else "f32 (x W^T products as split-bf16 bf16x3, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": args.workload, "vocab": V, "embed": E, "hidden": H, "y_size": y, "k": k,
@@ -266,7 +306,7 @@ def main():
                                "hi/lo-split fp32 operands, fp32 accumulate; same 1e-4 loss / exact greedy-id parity "
                                "tests pass, tests/test_bf16x3_mode_gpu.py). NOT the headline `value`, which is exact fp32.")
             out["split_bf16_mode"] = alt_res
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and args.workload in ("S-fixed", "P-fixed"):
             torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or torch.get_num_threads())
             tps, dt = cpu_baseline(V, E, H, y, k, T, args.cpu_sample)
             out["cpu_baseline"] = {"value": round(tps, 1), "unit": "tokens/s", "cores": torch.get_num_threads(),
