@@ -31,6 +31,16 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 
+// 128x128 tile with 4 waves (2x2, wave tile 64x64) or 8 waves (2x4, wave tile 64x32; 4 waves per SIMD at 2 blocks/CU)
+int big_tile_threads() {
+    static int v = 0;
+    if (v == 0) {
+        const char* e = getenv("LAED_GEMM_THREADS");
+        v = (e != nullptr && atoi(e) == 256) ? 256 : 512;
+    }
+    return v;
+}
+
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e;
@@ -54,12 +64,11 @@ struct SgemmArgs {
 };
 
 constexpr int BK = 32;
-constexpr int NT = 256;
 
 // Load a (BR rows) x (BK k) tile into registers as float4s.
 //  KCONTIG: element (r,k) at P[r*ld + k]   -> each thread takes 4 consecutive k of one row
 // !KCONTIG: element (r,k) at P[k*ld + r]   -> each thread takes 4 consecutive rows of one k
-template <bool KCONTIG, int BR, bool VEC>
+template <bool KCONTIG, int BR, bool VEC, int NT>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int r0, int k0, int R, int K,
                                           int tid, float4 (&reg)[BR * BK / 4 / NT]) {
     constexpr int NL = BR * BK / 4 / NT;
@@ -102,7 +111,7 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t l
 
 // Write the registers to the LDS image s[BK][S], S = BR + pad (pad 1 for KCONTIG: conflict-free transposing
 // b32 writes; pad 4 otherwise: 16-byte aligned b128 writes).
-template <bool KCONTIG, int BR>
+template <bool KCONTIG, int BR, int NT>
 __device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const float4 (&reg)[BR * BK / 4 / NT]) {
     constexpr int NL = BR * BK / 4 / NT;
     constexpr int S = BR + (KCONTIG ? 1 : 4);
@@ -123,20 +132,22 @@ __device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT>
 __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
     constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
     constexpr int SA = BM + (AK ? 1 : 4);
     constexpr int SB = BN + (BKC ? 1 : 4);
-    constexpr int TM = BM / 64, TN = BN / 64;
+    // waves form a 2 x WGN grid over the block tile (WGN = 2 for 256 threads, 4 for 512); wave tile (BM/2) x (BN/WGN)
+    constexpr int WGN = NT / 128;
+    constexpr int TM = BM / 64, TN = BN / WGN / 32;
     constexpr int NLA = BM * BK / 4 / NT, NLB = BN * BK / 4 / NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                 // [2][BK][SA]
     float* sB = smem + 2 * BK * SA;   // [2][BK][SB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware remap (bijective for any grid size), then grouped ordering over row tiles
     int nwg = gridDim.x, pid = blockIdx.x;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     const int lrow = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BK - 1) / BK;
     const float* a_base = sA + wm * (BM / 2) + lrow + lk * SA;   // fragment row (2*kk + lk) folded into the base
-    const float* b_base = sB + wn * (BN / 2) + lrow + lk * SB;
+    const float* b_base = sB + wn * (BN / WGN) + lrow + lk * SB;
 
     auto add_colsum = [&]() {
         if (TA && do_colsum) {
@@ -223,8 +234,8 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
 #pragma unroll
         for (int u = 0; u < NL; ++u) load_unit(u);
     } else {
-        tile_load<AK, BM, VEC>(p.A, p.lda, m0, kbeg, p.M, kend, tid, ra);
-        tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, kbeg, p.N, kend, tid, rb);
+        tile_load<AK, BM, VEC, NT>(p.A, p.lda, m0, kbeg, p.M, kend, tid, ra);
+        tile_load<BKC, BN, VEC, NT>(p.B, p.ldb, n0, kbeg, p.N, kend, tid, rb);
     }
     add_colsum();
 #pragma unroll
@@ -293,8 +304,8 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     for (; kt < nkt; ++kt) {
         const bool more = (kt + 1 < nkt);
         if (more) {
-            tile_load<AK, BM, VEC>(p.A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, kend, tid, ra);
-            tile_load<BKC, BN, VEC>(p.B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, kend, tid, rb);
+            tile_load<AK, BM, VEC, NT>(p.A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, kend, tid, ra);
+            tile_load<BKC, BN, VEC, NT>(p.B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, kend, tid, rb);
         }
         const float* a_s = a_base + cur * BK * SA;
         const float* b_s = b_base + cur * BK * SB;
@@ -313,8 +324,8 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
         }
         if (more) {
             add_colsum();
-            tile_store<AK, BM>(sA + (cur ^ 1) * BK * SA, tid, ra);
-            tile_store<BKC, BN>(sB + (cur ^ 1) * BK * SB, tid, rb);
+            tile_store<AK, BM, NT>(sA + (cur ^ 1) * BK * SA, tid, ra);
+            tile_store<BKC, BN, NT>(sB + (cur ^ 1) * BK * SB, tid, rb);
         }
         __syncthreads();
         cur ^= 1;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + lrow;
+            const int col = n0 + wn * (BN / WGN) + j * 32 + lrow;
             const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -393,11 +404,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs p) {
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256>
 int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
     constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
-    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC>;
+    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT>;
     static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -497,7 +508,8 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
             (void)hipEventRecord(r.stop, stream);
             g_prof_recs.push_back(r);
         }
-    } else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
+    } else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
+    else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
     else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
     if (st != 0 || S == 1 || raw_partials) return st;
     const int64_t mn = (int64_t)a.M * a.N;
