@@ -256,9 +256,11 @@ int gru_step(const GruStepArgs& a, hipStream_t stream) {
     if (forced_wm == 4) return launch_step<4, 1>(a, vec, stream);
     if (forced_wm == 2) return launch_step<2, 2>(a, vec, stream);
     if (forced_wm == 1) return launch_step<1, 4>(a, vec, stream);
-    // widest row tile that still yields >= 256 blocks (one per CU); tiny batches split K over the waves instead
-    if (a.B > 64 && cdiv64(a.B, 128) * jt >= 512) return launch_step<4, 1>(a, vec, stream);
-    if (a.B > 32 && cdiv64(a.B, 64) * jt >= 512) return launch_step<2, 2>(a, vec, stream);
+    // measured at H = 1024 (tools/gru_geom.py, us/step incl. the input GEMM share, B = 256 / 512 / 2048 / 4096):
+    //   128-row tiles 92 / 98 / 173 / 333,  64-row tiles 51 / 56 / 161 / 309,  32-row tiles (K split 4 ways) 39 / 70 / 256 / -
+    // 64-row tiles (41 KB of LDS: three blocks = 12 waves per CU) win from one block per CU upwards; smaller batches
+    // split K over all four waves of a 32-row tile instead.
+    if (a.B > 32 && cdiv64(a.B, 64) * jt >= 256) return launch_step<2, 2>(a, vec, stream);
     return launch_step<1, 4>(a, vec, stream);
 }
 
