@@ -86,11 +86,15 @@ int laed_uniform(float* u, int64_t n, uint64_t seed, uint64_t offset, void* stre
  *        gates is overwritten with d(gi); dgh[T][B][3H] is caller-provided workspace.
  *        accumulate_w != 0: weight/bias grads are added to the existing contents.
  *        ws (ws_floats floats, may be NULL): split-K scratch for small batches (see laed_sgemm_ws).
+ *  Small batches (B <= 64, H % 16 == 0) with a 16-byte aligned ws of at least laed_gru_*_workspace floats run the
+ *  packed-operand step kernels of gru_small.hip (W_hh re-laid once per call in MFMA lane order, activations handed
+ *  from step to step in the same order; backward = one fused launch per step); ws == NULL keeps the tiled kernels.
  * ------------------------------------------------------------------------------------------ */
+int64_t laed_gru_fwd_workspace(int T, int B, int E, int H);   /* ws_floats laed_gru_fwd can use (0: none) */
 int64_t laed_gru_bwd_workspace(int T, int B, int E, int H);   /* recommended ws_floats for laed_gru_bwd */
 int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  const float* h0, int T, int B, int E, int H,
-                 float* hbuf, float* gates, float* hn, void* stream);
+                 float* hbuf, float* gates, float* hn, float* ws, int64_t ws_floats, void* stream);
 int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh,
                  const float* hbuf, float* gates, const float* hn,
                  const float* dout, const float* dhT, int T, int B, int E, int H,

@@ -310,9 +310,15 @@ __global__ __launch_bounds__(256) void add_parts_kernel(float* __restrict__ y, c
 
 }   // namespace
 
+extern "C" int64_t laed_gru_fwd_workspace(int T, int B, int E, int H) {
+    (void)T; (void)E;
+    return laed_gru_small_ok(B, H) ? laed_gru_small_fwd_ws(B, H) : 0;       // packed W_hh + quad-major h ping-pong
+}
+
 extern "C" int64_t laed_gru_bwd_workspace(int T, int B, int E, int H) {
     const int64_t TBp = ((int64_t)T * B + 31) / 32 * 32;
     int64_t n = (int64_t)16 * B * H + (int64_t)8 * 3 * H * ((H > E ? H : E) + 1);          // split-K scratch
+    if (laed_gru_small_ok(B, H) && n < laed_gru_small_bwd_ws(B, H)) n = laed_gru_small_bwd_ws(B, H);
     if (laed_get_gemm_mode() == 1)
         n += (int64_t)3 * H * H + (int64_t)3 * H * E + (int64_t)3 * H * TBp + (int64_t)H * TBp;   // transposed operands
     return n;
@@ -327,7 +333,7 @@ int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh,
 
 extern "C" int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                             const float* h0, int T, int B, int E, int H,
-                            float* hbuf, float* gates, float* hn, void* stream_) {
+                            float* hbuf, float* gates, float* hn, float* ws, int64_t ws_floats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAED_CHECK_ARG(T > 0 && B > 0 && E > 0 && H > 0, "gru_fwd: non-positive dimension");
     LAED_CHECK_ARG(x && w_ih && w_hh && b_ih && b_hh && hbuf && gates, "gru_fwd: null pointer");
@@ -344,6 +350,9 @@ extern "C" int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh
     }
     // hoisted input projection for every timestep: gates[T*B][3H] = x[T*B][E] W_ih^T + b_ih
     LAED_TRY(laed_sgemm_impl(false, true, T * B, 3 * H, E, x, E, w_ih, E, gates, 3 * H, b_ih, false, nullptr, false, stream));
+    // small batches: packed-operand step kernels (gru_small.hip)
+    if (ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_fwd_ws(B, H))
+        return laed_gru_small_fwd(w_hh, b_hh, hbuf, gates, hn, T, B, H, ws, stream);
     for (int t = 0; t < T; ++t) {
         GruStepArgs a;
         a.hprev = hbuf + (int64_t)t * BH;
@@ -391,7 +400,10 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
         LAED_TRY(laed_transpose_impl(w_hh, H, 3 * H, H, WhhT, 3 * H, stream));
     }
     int nparts = 0;
-    for (int t = T - 1; t >= 0; --t) {
+    // small batches: one fused launch per step (gru_small.hip) over a packed copy of W_hh^T at the front of ws
+    const bool small = ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_bwd_ws(B, H);
+    if (small) LAED_TRY(laed_gru_small_bwd(w_hh, hbuf, hn, dout, gates, dgh, dh0, T, B, H, ws, stream));
+    for (int t = small ? -1 : T - 1; t >= 0; --t) {
         GruBwdStepArgs a;
         a.parts = ws;
         a.nparts = nparts;

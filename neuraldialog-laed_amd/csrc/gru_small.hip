@@ -1,0 +1,351 @@
+// GRU timestep kernels for SMALL batches (B <= 64: the reference's own script shapes, B = 30 / 60).
+//
+// At these sizes a timestep is ~50 MFLOP against 3-12 MB of recurrent weights: what matters is how many CUs pull
+// W_hh out of L2 at once and how short the dependent chain inside the kernel is, not MFMA throughput.  The tiled
+// kernel of gru.hip gives such a step 16 workgroups that each stream 196 KB through LDS (24.5 us at B = 30, H = 512).
+// Here a workgroup owns 4 (forward) / 8 (backward) hidden units, so the grid is H/4 or H/8 workgroups, and no
+// operand is staged in LDS: both MFMA operands are kept in memory in the order the lanes consume them.
+//   * v_mfma_f32_16x16x4_f32: lane (i = lane % 16, kq = lane / 16) supplies A[i][kq] and B[kq][i].  The contraction
+//     is order-free, so lane kq takes a whole QUAD of consecutive k-values (one float4) and feeds its four elements
+//     to four successive MFMAs -- both operands use the same permutation.
+//   * activations travel between the steps in "quad-major" form X[K/4][BP][4] (BP = batch rows padded to 16): the
+//     16 lanes of a row tile read 256 contiguous bytes.  Each step's epilogue writes its units' slice of the next
+//     step's operand in that form (besides the plain [B][H] tensors the rest of the library reads).
+//   * W_hh is packed once per call into per-workgroup P[K/4][NC][4] slabs (NC = 12 forward: r,z,n of 4 units;
+//     8 backward), again one float4 per lane per quad.
+//   * 8 waves split K; the partial 16x16 tiles meet in LDS, one thread per (batch row, hidden unit) sums them in a
+//     fixed order and applies the gate math.
+// forward : one launch per step, W_hh[3H][H] read once per step by H/4 workgroups.
+// backward: ONE launch per step instead of two: workgroup j-slice forms dh_t[:, slice] = carry + dgh_{t+1} W_hh[:, slice]
+//           (needs all of dgh_{t+1}: the kernel boundary) and goes straight on to the gate gradients of step t for
+//           its slice.
+#include "laed_common.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int NTH = 512;        // 8 waves
+constexpr int NW = NTH / 64;
+constexpr int UF = 4;           // hidden units per workgroup, forward  (12 of 16 MFMA columns)
+constexpr int UB = 8;           // hidden units per workgroup, backward ( 8 of 16 MFMA columns)
+constexpr int CH = 4;           // quad groups (16 k-values each) per load chunk
+
+// acc[rt] += X[rows 16 rt + i][k] * P[k][col i] over this wave's share of K (ngrp groups of 4 quads).
+template <int RT, int NC>
+__device__ __forceinline__ void small_core(const float* __restrict__ x, const float* __restrict__ pw, int ngrp, int wave, int lane,
+                                           f32x4 (&acc)[RT]) {
+    constexpr int BP = 16 * RT;
+    const int li = lane & 15, kq = lane >> 4;
+    const bool bval = li < NC;
+    const int q0 = wave * 4 * ngrp + kq;
+    const float4* ap = reinterpret_cast<const float4*>(x) + (int64_t)q0 * BP + li;
+    const float4* bp = reinterpret_cast<const float4*>(pw) + (int64_t)q0 * NC + (bval ? li : 0);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a0[CH][RT], b0[CH], a1[CH][RT], b1[CH];
+    auto ld = [&](float4 (&a)[CH][RT], float4 (&b)[CH], int g0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int g = g0 + c;
+            if (g < ngrp) {                       // wave-uniform
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[c][rt] = ap[(int64_t)4 * g * BP + rt * 16];
+                b[c] = bval ? bp[(int64_t)4 * g * NC] : z4;
+            }
+        }
+    };
+    auto mm = [&](const float4 (&a)[CH][RT], const float4 (&b)[CH], int g0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (g0 + c < ngrp) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][rt].x, b[c].x, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][rt].y, b[c].y, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][rt].z, b[c].z, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][rt].w, b[c].w, acc[rt], 0, 0, 0);
+            }
+        }
+    };
+    ld(a0, b0, 0);
+    for (int g0 = 0; g0 < ngrp; g0 += 2 * CH) {       // chunk g0+CH is in flight while chunk g0 multiplies
+        if (g0 + CH < ngrp) ld(a1, b1, g0 + CH);
+        mm(a0, b0, g0);
+        if (g0 + 2 * CH < ngrp) ld(a0, b0, g0 + 2 * CH);
+        if (g0 + CH < ngrp) mm(a1, b1, g0 + CH);
+    }
+}
+
+// partial tiles -> LDS red[wave][row BP][NC]   (C/D map of 16x16x4: col = lane % 16, row = 4 * (lane / 16) + e)
+template <int RT, int NC>
+__device__ __forceinline__ void spill_partials(float* red, const f32x4 (&acc)[RT], int wave, int lane) {
+    constexpr int BP = 16 * RT;
+    const int col = lane & 15, kq = lane >> 4;
+    if (col < NC) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(wave * BP + rt * 16 + 4 * kq + e) * NC + col] = acc[rt][e];
+    }
+}
+
+template <int RT, int NC>
+__device__ __forceinline__ float sum_partials(const float* red, int nkw, int row, int col) {
+    constexpr int BP = 16 * RT;
+    float s = 0.f;
+    for (int w = 0; w < nkw; ++w) s += red[(w * BP + row) * NC + col];   // fixed order
+    return s;
+}
+
+struct SmallFwdArgs {
+    const float* hx_in;     // [H/4][BP][4] h_{t-1}, quad-major
+    const float* wp;        // [H/UF][H/4][3 UF][4] packed W_hh
+    const float* b_hh;
+    const float* hprev;     // [B][H]
+    float* gates;           // [B][3H] in: gi (+b_ih), out: r,z,n
+    float* hout;            // [B][H]
+    float* hn;              // [B][H] or NULL
+    float* hx_out;          // [H/4][BP][4] h_t, quad-major
+    int B, H, nkw;          // nkw waves split K (H % (16 nkw) == 0)
+};
+
+template <int RT>
+__global__ __launch_bounds__(NTH) void gru_small_fwd_kernel(SmallFwdArgs p) {
+    constexpr int NC = 3 * UF, BP = 16 * RT;
+    __shared__ float red[NW * BP * NC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, B = p.B, j0 = blockIdx.x * UF;
+    // epilogue operands of this thread's (row, unit) pair: fetched now, needed after the reduction
+    const int row = tid / UF, u = tid % UF, j = j0 + u;
+    const bool mine = row < B;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f;
+    float* g = p.gates + (int64_t)row * 3 * H;
+    if (mine) {
+        gi_r = g[j]; gi_z = g[H + j]; gi_n = g[2 * H + j];
+        hp = p.hprev[(int64_t)row * H + j];
+        bhr = p.b_hh[j]; bhz = p.b_hh[H + j]; bhn = p.b_hh[2 * H + j];
+    }
+    if (wave < p.nkw) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
+        small_core<RT, NC>(p.hx_in, p.wp + (int64_t)blockIdx.x * H * NC, H / 16 / p.nkw, wave, lane, acc);
+        spill_partials<RT, NC>(red, acc, wave, lane);
+    }
+    __syncthreads();
+    if (row >= BP) return;
+    float h = 0.f;
+    if (mine) {
+        const float ghr = sum_partials<RT, NC>(red, p.nkw, row, u), ghz = sum_partials<RT, NC>(red, p.nkw, row, UF + u);
+        const float ghn = sum_partials<RT, NC>(red, p.nkw, row, 2 * UF + u) + bhn;
+        const float r = sigmoidf_acc(gi_r + ghr + bhr);
+        const float z = sigmoidf_acc(gi_z + ghz + bhz);
+        const float n = tanhf(gi_n + r * ghn);
+        h = (1.0f - z) * n + z * hp;
+        p.hout[(int64_t)row * H + j] = h;
+        if (p.hn != nullptr) {
+            g[j] = r; g[H + j] = z; g[2 * H + j] = n;
+            p.hn[(int64_t)row * H + j] = ghn;
+        }
+    }
+    p.hx_out[((int64_t)(j / 4) * BP + row) * 4 + (j & 3)] = h;      // padding rows carry zeros
+}
+
+struct SmallBwdArgs {
+    const float* dx_in;      // [3H/4][BP][4] dgh of step t+1, quad-major, or NULL at the first (last-time) step
+    const float* wpT;        // [H/UB][3H/4][UB][4] packed W_hh^T
+    const float* dout;       // [B][H] or NULL
+    const float* hprev;      // [B][H]
+    const float* hn;         // [B][H]
+    float* gates;            // [B][3H] in: r,z,n  out: d(gi)
+    float* dgh;              // [B][3H] out (step t)
+    float* dx_out;           // [3H/4][BP][4] out (step t), quad-major
+    float* dh;               // [B][H] carry: in dh_{t+1}*z_{t+1} (without the W_hh term), out dh_t*z_t; final: out dh_0
+    int B, H, nkw, final_step;
+};
+
+template <int RT>
+__global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
+    constexpr int NC = UB, BP = 16 * RT;
+    __shared__ float red[NW * BP * NC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, B = p.B, j0 = blockIdx.x * UB, K = 3 * H;
+    const int row = tid / UB, u = tid % UB, j = j0 + u;
+    const bool mine = row < B;
+    const int64_t i = (int64_t)row * H + j;
+    float dh = 0.f, r = 0.f, z = 0.f, nn = 0.f, hnv = 0.f, hp = 0.f;
+    float* g = p.gates + (int64_t)row * 3 * H;
+    if (mine) {
+        dh = p.dh[i];
+        if (!p.final_step) {
+            if (p.dout != nullptr) dh += p.dout[i];
+            r = g[j]; z = g[H + j]; nn = g[2 * H + j];
+            hnv = p.hn[i]; hp = p.hprev[i];
+        }
+    }
+    if (p.dx_in != nullptr) {        // block-uniform
+        if (wave < p.nkw) {
+            f32x4 acc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
+            small_core<RT, NC>(p.dx_in, p.wpT + (int64_t)blockIdx.x * K * NC, K / 16 / p.nkw, wave, lane, acc);
+            spill_partials<RT, NC>(red, acc, wave, lane);
+        }
+        __syncthreads();
+        if (mine) dh += sum_partials<RT, NC>(red, p.nkw, row, u);
+    }
+    if (row >= BP) return;
+    if (p.final_step) { if (mine) p.dh[i] = dh; return; }
+    float drp = 0.f, dzp = 0.f, dnr = 0.f;
+    if (mine) {
+        float* d = p.dgh + (int64_t)row * 3 * H;
+        const float dn = dh * (1.0f - z);
+        const float dz = dh * (hp - nn);
+        const float dnp = dn * (1.0f - nn * nn);
+        dzp = dz * z * (1.0f - z);
+        drp = dnp * hnv * r * (1.0f - r);
+        dnr = dnp * r;
+        g[j] = drp; g[H + j] = dzp; g[2 * H + j] = dnp;
+        d[j] = drp; d[H + j] = dzp; d[2 * H + j] = dnr;
+        p.dh[i] = dh * z;
+    }
+    const int e4 = j & 3;
+    p.dx_out[((int64_t)(j / 4) * BP + row) * 4 + e4] = drp;           // padding rows carry zeros
+    p.dx_out[((int64_t)((H + j) / 4) * BP + row) * 4 + e4] = dzp;
+    p.dx_out[((int64_t)((2 * H + j) / 4) * BP + row) * 4 + e4] = dnr;
+}
+
+// wp[wg][q][c][e] = W_hh[(c / UF) H + wg UF + c % UF][4q + e]      (one float4 per thread)
+__global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wp) {
+    constexpr int NC = 3 * UF;
+    const int64_t n = (int64_t)(H / UF) * (H / 4) * NC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NC);
+        const int q = (int)((i / NC) % (H / 4));
+        const int wg = (int)(i / NC / (H / 4));
+        const float* s = w_hh + ((int64_t)(c / UF) * H + wg * UF + c % UF) * H + 4 * q;
+        float* d = wp + i * 4;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+    }
+}
+
+// wpT[wg][q][c][e] = W_hh[4q + e][wg UB + c],  q < 3H/4
+__global__ __launch_bounds__(256) void pack_w_bwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wpT) {
+    const int64_t n = (int64_t)(H / UB) * (3 * H / 4) * UB;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % UB);
+        const int q = (int)((i / UB) % (3 * H / 4));
+        const int wg = (int)(i / UB / (3 * H / 4));
+        const float* s = w_hh + (int64_t)(4 * q) * H + wg * UB + c;
+        float* d = wpT + i * 4;
+        d[0] = s[0]; d[1] = s[H]; d[2] = s[2 * (int64_t)H]; d[3] = s[3 * (int64_t)H];
+    }
+}
+
+// xq[q][row][e] = row < B ? m[row][4q + e] : 0      (K = row length of m, BP padded rows)
+__global__ __launch_bounds__(256) void rows_to_quads_kernel(const float* __restrict__ m, int B, int K, int BP, float* __restrict__ xq) {
+    const int64_t n = (int64_t)(K / 4) * BP;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i % BP);
+        const int q = (int)(i / BP);
+        float* d = xq + i * 4;
+        if (row < B) {
+            const float* s = m + (int64_t)row * K + 4 * q;
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+        } else {
+            d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; d[3] = 0.f;
+        }
+    }
+}
+
+bool small_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LAED_GRU_SMALL"); v = (e != nullptr && atoi(e) == 0) ? 0 : 1; }
+    return v == 1;
+}
+
+// largest K split (waves) with K % (16 nkw) == 0
+int k_waves(int K) {
+    for (int w = NW; w > 1; w >>= 1)
+        if (K % (16 * w) == 0) return w;
+    return 1;
+}
+
+template <typename A, typename K1, typename K2, typename K3, typename K4>
+void launch_rt(int B, dim3 grid, hipStream_t stream, const A& a, K1 k1, K2 k2, K3 k3, K4 k4) {
+    if (B <= 16) hipLaunchKernelGGL(k1, grid, dim3(NTH), 0, stream, a);
+    else if (B <= 32) hipLaunchKernelGGL(k2, grid, dim3(NTH), 0, stream, a);
+    else if (B <= 48) hipLaunchKernelGGL(k3, grid, dim3(NTH), 0, stream, a);
+    else hipLaunchKernelGGL(k4, grid, dim3(NTH), 0, stream, a);
+}
+
+}   // namespace
+
+// B <= 64 rows, H a multiple of 16 (quads, whole MFMA k-groups, whole unit slices)
+bool laed_gru_small_ok(int B, int H) {
+    return small_enabled() && getenv("LAED_GRU_WM") == nullptr && B >= 1 && B <= 64 && H >= 16 && (H % 16) == 0;
+}
+
+int laed_gru_small_bp(int B) { return (B + 15) / 16 * 16; }
+
+int64_t laed_gru_small_fwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * H * laed_gru_small_bp(B); }
+int64_t laed_gru_small_bwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * 3 * H * laed_gru_small_bp(B); }
+
+// forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
+int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
+                       float* ws, hipStream_t stream) {
+    const int BP = laed_gru_small_bp(B);
+    const int64_t BH = (int64_t)B * H;
+    float* wp = ws;
+    float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP};
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wp);
+    LAED_LAUNCH_CHECK("gru_small pack_w_fwd");
+    hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, hx[0]);
+    LAED_LAUNCH_CHECK("gru_small rows_to_quads");
+    for (int t = 0; t < T; ++t) {
+        SmallFwdArgs a;
+        a.hx_in = hx[t & 1]; a.wp = wp; a.b_hh = b_hh; a.hprev = hbuf + (int64_t)t * BH;
+        a.gates = gates + (int64_t)t * B * 3 * H; a.hout = hbuf + (int64_t)(t + 1) * BH;
+        a.hn = hn ? hn + (int64_t)t * BH : nullptr; a.hx_out = hx[(t + 1) & 1];
+        a.B = B; a.H = H; a.nkw = k_waves(H);
+        launch_rt(B, dim3(H / UF), stream, a, gru_small_fwd_kernel<1>, gru_small_fwd_kernel<2>, gru_small_fwd_kernel<3>,
+                  gru_small_fwd_kernel<4>);
+        LAED_LAUNCH_CHECK("gru_small_fwd");
+    }
+    return 0;
+}
+
+// backward recurrence over all T steps (gate gradients + dh chain); dh0 holds dh_T on entry and dh_0 on return.
+// ws: laed_gru_small_bwd_ws floats, 16-byte aligned.
+int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, float* gates, float* dgh,
+                       float* dh0, int T, int B, int H, float* ws, hipStream_t stream) {
+    const int BP = laed_gru_small_bp(B);
+    const int64_t BH = (int64_t)B * H;
+    float* wpT = ws;
+    float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP};
+    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT);
+    LAED_LAUNCH_CHECK("gru_small pack_w_bwd");
+    for (int t = T - 1; t >= -1; --t) {
+        SmallBwdArgs a;
+        const bool fin = t < 0;
+        a.dx_in = t == T - 1 ? nullptr : dx[(t + 1) & 1];
+        a.wpT = wpT;
+        a.dout = (!fin && dout) ? dout + (int64_t)t * BH : nullptr;
+        a.hprev = fin ? nullptr : hbuf + (int64_t)t * BH;
+        a.hn = fin ? nullptr : hn + (int64_t)t * BH;
+        a.gates = fin ? nullptr : gates + (int64_t)t * B * 3 * H;
+        a.dgh = fin ? nullptr : dgh + (int64_t)t * B * 3 * H;
+        a.dx_out = fin ? nullptr : dx[t & 1];
+        a.dh = dh0; a.B = B; a.H = H; a.nkw = k_waves(3 * H); a.final_step = fin ? 1 : 0;
+        launch_rt(B, dim3(H / UB), stream, a, gru_small_bwd_kernel<1>, gru_small_bwd_kernel<2>, gru_small_bwd_kernel<3>,
+                  gru_small_bwd_kernel<4>);
+        LAED_LAUNCH_CHECK("gru_small_bwd");
+    }
+    return 0;
+}

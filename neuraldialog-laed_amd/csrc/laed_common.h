@@ -61,6 +61,15 @@ int laed_sgemm_rowsum_impl(int M, int N, int K, const float* A, int64_t lda, con
 int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh, float* gates, float* hout, float* hn,
                        int B, int H, hipStream_t stream);
 
+// small-batch GRU recurrences (gru_small.hip): B <= 64, H % 16 == 0; ws 16-byte aligned, laed_gru_small_*_ws floats
+bool laed_gru_small_ok(int B, int H);
+int64_t laed_gru_small_fwd_ws(int B, int H);
+int64_t laed_gru_small_bwd_ws(int B, int H);
+int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
+                       float* ws, hipStream_t stream);
+int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, float* gates, float* dgh,
+                       float* dh0, int T, int B, int H, float* ws, hipStream_t stream);
+
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -180,6 +180,15 @@ def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_i
 # ----------------------------------------------------------------------------------------------
 # autograd glue
 # ----------------------------------------------------------------------------------------------
+def _single_use(ctx, name):
+    """GRUFunction / ProjNLLFunction rewrite their saved buffers in place during backward (reserve-space style), so a
+    second backward over the same graph (retain_graph=True) would silently produce wrong gradients: refuse it."""
+    if getattr(ctx, "_laed_consumed", False):
+        raise RuntimeError("%s: backward was already run on this graph; its saved buffers are single-use "
+                           "(re-run the forward pass instead of retain_graph=True)" % name)
+    ctx._laed_consumed = True
+
+
 class EmbedFunction(torch.autograd.Function):
     """out[rows,E] = weight[ids] (* keep/(1-p)); PAD rows get no gradient."""
 
@@ -245,8 +254,10 @@ class GRUFunction(torch.autograd.Function):
         gates = torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32)
         hn = torch.empty((T, B, H), device=dev, dtype=torch.float32)
         h0c = _f32c(h0) if h0 is not None else None
+        ws_n = int(lib.laed_gru_fwd_workspace(T, B, E, H))         # packed operands of the small-batch step kernels
+        ws = workspace("gru_ws", ws_n, dev) if ws_n > 0 else None
         check(lib.laed_gru_fwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(h0c), T, B, E, H,
-                               ptr(hbuf), ptr(gates), ptr(hn), stream()), "laed_gru_fwd")
+                               ptr(hbuf), ptr(gates), ptr(hn), ptr(ws), ws_n, stream()), "laed_gru_fwd")
         ctx.save_for_backward(x, w_ih, w_hh, hbuf, gates, hn)
         ctx.has_h0 = h0 is not None
         out = hbuf[1:]
@@ -255,6 +266,7 @@ class GRUFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, dhT):
+        _single_use(ctx, "GRUFunction")
         x, w_ih, w_hh, hbuf, gates, hn = ctx.saved_tensors
         T, B, E = x.shape
         H = w_hh.shape[1]
@@ -371,6 +383,7 @@ class ProjNLLFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dtok):
+        _single_use(ctx, "ProjNLLFunction")
         dh, dW, db = ctx.saved_tensors
         g = _f32c(dloss).reshape(1)
         for t in (dh, dW, db):

@@ -40,7 +40,7 @@ def test_argument_validation_without_a_device():
     assert lib.laed_gumbel_latent_fwd(None, None, 10, 65, 1.0, 0, None, None, None, None) == -1
     assert b"k <= 64" in lib.laed_last_error()
     assert lib.laed_gumbel_latent_fwd(None, None, 10, 10, 0.0, 0, None, None, None, None) == -1
-    assert lib.laed_gru_fwd(None, None, None, None, None, None, 0, 1, 1, 1, None, None, None, None) == -1
+    assert lib.laed_gru_fwd(None, None, None, None, None, None, 0, 1, 1, 1, None, None, None, None, 0, None) == -1
     assert lib.laed_adam_step(None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) == -1
     assert lib.laed_proj_nll_ldl(50000) == 50016 and lib.laed_proj_nll_ldl(10002) == 10016
     assert lib.laed_latent_stats_blocks() > 0

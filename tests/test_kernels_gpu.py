@@ -158,6 +158,14 @@ def test_gru_fwd_bwd(ops, O, T, B, E, H, with_h0):
     _gru_case(ops, O, T, B, E, H, with_h0, seed=10, tol=1e-5)
 
 
+@pytest.mark.parametrize("T,B,E,H,with_h0", [(4, 1, 8, 64, True), (6, 30, 24, 128, False), (5, 33, 16, 192, True),
+                                             (3, 64, 40, 1024, True), (9, 60, 200, 512, False), (1, 16, 8, 16, True),
+                                             (4, 45, 12, 80, False), (5, 17, 16, 48, True), (7, 30, 200, 512, True)])
+def test_gru_small_batch_kernels(ops, O, T, B, E, H, with_h0):
+    """B <= 64 and H % 16 == 0 take gru_small.hip (packed operands, 4 / 8 units per workgroup, fused backward step)."""
+    _gru_case(ops, O, T, B, E, H, with_h0, seed=30, tol=1e-5)
+
+
 def test_gru_all_tile_configs(ops, O):
     # the block-tile choice is a pure launch-geometry decision: every forced config must agree
     try:
@@ -336,3 +344,23 @@ def test_argmax_logsoftmax_greedy(ops, O):
     top2 = logp_c.topk(2, dim=2)[0]
     assert float((top2[..., 0] - top2[..., 1]).min()) > 1e-4   # fixture has no near-ties
     assert np.array_equal(ids_g.t().cpu().numpy(), seq_c.numpy())
+
+
+def test_single_use_tapes_refuse_a_second_backward():
+    """GRU / fused projection rewrite their saved buffers in backward; a retained graph must not be run twice."""
+    from laed_amd import ops
+    x = torch.randn(3, 4, 6, device="cuda", requires_grad=True)
+    w_ih, w_hh = torch.randn(24, 6, device="cuda", requires_grad=True), torch.randn(24, 8, device="cuda", requires_grad=True)
+    b = torch.zeros(24, device="cuda", requires_grad=True)
+    out, hT = ops.GRUFunction.apply(x, w_ih, w_hh, b, b, None)
+    loss = out.sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="single-use"):
+        loss.backward()
+    h = torch.randn(10, 8, device="cuda", requires_grad=True)
+    W, bb = torch.randn(17, 8, device="cuda", requires_grad=True), torch.zeros(17, device="cuda", requires_grad=True)
+    labels = torch.randint(1, 17, (10,), device="cuda")
+    l2, _ = ops.ProjNLLFunction.apply(h, W, bb, labels, torch.full((10,), 0.1, device="cuda"), 0)
+    l2.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="single-use"):
+        l2.backward()
