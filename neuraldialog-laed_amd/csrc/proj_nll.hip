@@ -11,6 +11,7 @@
 // A forward-only call (with_grad = 0: validation) stops after step 2 without the in-place rewrite.
 #include "laed_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -109,6 +110,112 @@ __global__ __launch_bounds__(256) void proj_rows_kernel(float* __restrict__ L, i
             for (int i = V4 * 4 + tid; i < V; i += 256) Lr[i] -= lse;
         }
         __syncthreads();   // sm/ss/s_lab reused by the next row
+    }
+}
+
+// Register-resident variant: one 1024-thread block holds a whole row (NV float4 per thread, V <= 4096 NV), so the
+// row is read ONCE and written once (2 passes over the [rows][ldl] workspace instead of 3): exact two-step softmax
+// (row max, then sum of exp(x - max)), the exponentials are kept and reused for the gradient.
+template <int MODE, int NV>
+__global__ __launch_bounds__(1024) void proj_rows_reg_kernel(float* __restrict__ L, int64_t rows, int V, int64_t ldl,
+                                                             const int64_t* __restrict__ labels, const float* __restrict__ row_scale,
+                                                             int64_t pad_id, float* __restrict__ tok_nll, float* __restrict__ lse_out) {
+    __shared__ float sred[2][16];
+    __shared__ float s_lab;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n4 = (int)(ldl >> 2);
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        float4* Lr4 = reinterpret_cast<float4*>(L + row * ldl);
+        const int64_t lab = (labels != nullptr) ? labels[row] : -1;
+        const bool ignored = (labels != nullptr) && (lab == pad_id || lab < 0 || lab >= V);
+        if (MODE == MODE_GRAD && ignored) {   // ignored rows: zero loss, zero gradient
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int i = tid + 1024 * c;
+                if (i < n4) Lr4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (tid == 0) { tok_nll[row] = 0.f; if (lse_out) lse_out[row] = 0.f; }
+            continue;
+        }
+        float4 x[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int i = tid + 1024 * c;
+            x[c] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (i < n4) {
+                x[c] = Lr4[i];
+                const int c0 = 4 * i;                  // columns >= V are workspace padding
+                if (c0 + 3 >= V) {
+                    if (c0 >= V) x[c].x = -INFINITY;
+                    if (c0 + 1 >= V) x[c].y = -INFINITY;
+                    if (c0 + 2 >= V) x[c].z = -INFINITY;
+                    x[c].w = -INFINITY;
+                }
+            }
+        }
+        const int lab_i = ignored ? -1 : (int)lab;
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            m = fmaxf(m, fmaxf(fmaxf(x[c].x, x[c].y), fmaxf(x[c].z, x[c].w)));
+            const int c0 = 4 * (tid + 1024 * c);
+            if (lab_i >= c0 && lab_i < c0 + 4)
+                s_lab = lab_i == c0 ? x[c].x : (lab_i == c0 + 1 ? x[c].y : (lab_i == c0 + 2 ? x[c].z : x[c].w));
+        }
+        m = wave_max(m);
+        if (lane == 0) sred[0][wave] = m;
+        __syncthreads();
+        m = sred[0][0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, sred[0][w]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {          // exp(-inf - m) = 0 for padding
+            x[c].x = expf(x[c].x - m); x[c].y = expf(x[c].y - m); x[c].z = expf(x[c].z - m); x[c].w = expf(x[c].w - m);
+            sum += (x[c].x + x[c].y) + (x[c].z + x[c].w);
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) sred[1][wave] = sum;
+        __syncthreads();
+        sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += sred[1][w];     // fixed order
+        const float lg = logf(sum);
+        const float lse = m + lg;
+        if (tid == 0) {
+            if (lse_out) lse_out[row] = lse;
+            if (tok_nll) tok_nll[row] = ignored ? 0.f : (labels != nullptr ? lse - s_lab : 0.f);
+        }
+        if (MODE == MODE_GRAD) {
+            const float g = row_scale ? row_scale[row] : 1.0f;
+            const float sc = g / sum;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int i = tid + 1024 * c;
+                if (i < n4) {
+                    float4 v = x[c];
+                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    const int c0 = 4 * i;
+                    if (lab_i >= c0 && lab_i < c0 + 4) {
+                        if (lab_i == c0) v.x -= g; else if (lab_i == c0 + 1) v.y -= g;
+                        else if (lab_i == c0 + 2) v.z -= g; else v.w -= g;
+                    }
+                    Lr4[i] = v;
+                }
+            }
+        } else if (MODE == MODE_LOGP) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int i = tid + 1024 * c;
+                if (i < n4) {
+                    float4 v = x[c];        // log(exp(x - m)) would lose precision: recompute from the stored logits
+                    const float4 o = Lr4[i];
+                    v.x = o.x - lse; v.y = o.y - lse; v.z = o.z - lse; v.w = o.w - lse;
+                    Lr4[i] = v;
+                }
+            }
+        }
+        __syncthreads();   // sred / s_lab reused by the next row
     }
 }
 
@@ -227,6 +334,29 @@ namespace {
 
 inline int rows_grid(int64_t rows) { return (int)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
 
+template <int MODE>
+int launch_rows(float* L, int64_t rows, int V, int64_t ldl, const int64_t* labels, const float* row_scale, int64_t pad_id,
+                float* tok_nll, float* lse, hipStream_t stream) {
+    const int64_t need = cdiv64(ldl / 4, 1024);     // float4 per thread for a register-resident row
+    static const bool reg_on = []() { const char* e = getenv("LAED_PROJ_ROWS_REG"); return !(e != nullptr && atoi(e) == 0); }();
+    const dim3 grid(rows_grid(rows));
+#define LAED_ROWS_REG(NV) hipLaunchKernelGGL((proj_rows_reg_kernel<MODE, NV>), grid, dim3(1024), 0, stream, L, rows, V, ldl, labels, \
+                                             row_scale, pad_id, tok_nll, lse)
+    if (reg_on && ldl % 4 == 0 && need <= 16) {
+        if (need <= 1) LAED_ROWS_REG(1);
+        else if (need <= 2) LAED_ROWS_REG(2);
+        else if (need <= 4) LAED_ROWS_REG(4);
+        else if (need <= 8) LAED_ROWS_REG(8);
+        else if (need <= 13) LAED_ROWS_REG(13);
+        else LAED_ROWS_REG(16);
+    } else {
+        hipLaunchKernelGGL((proj_rows_kernel<MODE>), grid, dim3(256), 0, stream, L, rows, V, ldl, labels, row_scale, pad_id, tok_nll, lse);
+    }
+#undef LAED_ROWS_REG
+    LAED_LAUNCH_CHECK("proj_rows");
+    return 0;
+}
+
 }   // namespace
 
 // dh = dl W has only (rows/128) x (H/128) output tiles but K = V is long: chunks that do not fill whole rounds of the
@@ -275,12 +405,11 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
         const float* hc = h + r0 * H;
         LAED_TRY(laed_sgemm_impl(false, true, rows, V, H, hc, H, W, H, workspace, ldl, b, false, nullptr, false, stream));
         if (with_grad)
-            hipLaunchKernelGGL((proj_rows_kernel<MODE_GRAD>), dim3(rows_grid(rows)), dim3(256), 0, stream, workspace, (int64_t)rows, V,
-                               ldl, labels + r0, row_scale ? row_scale + r0 : nullptr, pad_id, tok_nll + r0, lse ? lse + r0 : nullptr);
+            LAED_TRY(launch_rows<MODE_GRAD>(workspace, (int64_t)rows, V, ldl, labels + r0, row_scale ? row_scale + r0 : nullptr, pad_id,
+                                            tok_nll + r0, lse ? lse + r0 : nullptr, stream));
         else
-            hipLaunchKernelGGL((proj_rows_kernel<MODE_STATS>), dim3(rows_grid(rows)), dim3(256), 0, stream, workspace, (int64_t)rows, V,
-                               ldl, labels + r0, nullptr, pad_id, tok_nll + r0, lse ? lse + r0 : nullptr);
-        LAED_LAUNCH_CHECK("proj_rows");
+            LAED_TRY(launch_rows<MODE_STATS>(workspace, (int64_t)rows, V, ldl, labels + r0, nullptr, pad_id, tok_nll + r0,
+                                             lse ? lse + r0 : nullptr, stream));
         if (with_grad && xmode) {
             // dh = dl W  as  dl [rows][V] x (W^T [H][V])^T ;  dW += dl^T h  as  dl^T [V][rows] x (h^T [H][rows])^T
             LAED_TRY(laed_sgemm_impl(false, true, rows, H, V, workspace, ldl, WT, ldl, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
@@ -303,10 +432,7 @@ extern "C" int laed_log_softmax_rows(float* logits, int64_t N, int V, int ldl, f
     LAED_CHECK_ARG(N >= 0 && V > 0 && ldl >= V && ldl % 4 == 0, "log_softmax_rows: bad size (ldl must be a multiple of 4)");
     if (N == 0) return 0;
     LAED_CHECK_ARG(logits && aligned16(logits), "log_softmax_rows: null or unaligned pointer");
-    hipLaunchKernelGGL((proj_rows_kernel<MODE_LOGP>), dim3(rows_grid(N)), dim3(256), 0, (hipStream_t)stream, logits, N, V,
-                       (int64_t)ldl, (const int64_t*)nullptr, (const float*)nullptr, (int64_t)-1, (float*)nullptr, lse);
-    LAED_LAUNCH_CHECK("log_softmax_rows");
-    return 0;
+    return launch_rows<MODE_LOGP>(logits, N, V, (int64_t)ldl, nullptr, nullptr, (int64_t)-1, nullptr, lse, (hipStream_t)stream);
 }
 
 extern "C" int laed_argmax_rows(const float* logits, int64_t N, int V, int ldl, int64_t* ids, void* stream) {
