@@ -421,7 +421,9 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
         } else if (with_grad) {
             LAED_TRY(laed_sgemm_splitk_impl(false, false, rows, H, V, workspace, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr,
                                             false, dh_ws, dh_ws_floats, false, nullptr, stream));
-            LAED_TRY(laed_sgemm_impl(true, false, V, H, rows, workspace, ldl, hc, H, dW, H, nullptr, acc, db, acc, stream));
+            //   (dh_ws is free again: the dh product above has consumed its partials in stream order)
+            LAED_TRY(laed_sgemm_splitk_impl(true, false, V, H, rows, workspace, ldl, hc, H, dW, H, nullptr, acc, db, acc,
+                                            dh_ws, dh_ws_floats, false, nullptr, stream));
             acc = true;
         }
     }

@@ -15,6 +15,7 @@
 #include "laed_common.h"
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
@@ -254,10 +255,14 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
         gb += b_step;
 #pragma unroll
         for (int u = 0; u < NL; ++u) load_unit(u);
-        for (; kt + 1 < nfull; ++kt) {
-            const float* a_s = a_base + cur * BK * SA;
-            const float* b_s = b_base + cur * BK * SB;
-            if (kt + 2 < nfull) { ga += a_step; gb += b_step; }
+        // one K tile out of LDS buffer CUR (compile-time, so that every LDS offset of the body is an immediate)
+        auto tile_body = [&](auto cur_c, bool advance) {
+            constexpr int CUR = decltype(cur_c)::value;
+            const float* a_s = a_base + CUR * BK * SA;
+            const float* b_s = b_base + CUR * BK * SB;
+#if !defined(SGEMM_EXP) || !(SGEMM_EXP & 32)
+            if (advance) { ga += a_step; gb += b_step; }
+#endif
             // fragments are read TWO k pairs ahead (three register sets): the wait before a k pair's first MFMA then
             // covers reads issued a whole k pair (>= 256 cycles) earlier and leaves the newest reads in flight
             // (counted lgkmcnt), which is what one or two waves per SIMD need to keep the LDS latency off the MFMA chain
@@ -277,27 +282,53 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
                     for (int j = 0; j < TN; ++j) {
                         const int q_ = kk * NMF + i * TN + j;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk % 3][i], bf[kk % 3][j], acc[i][j], 0, 0, 0);
+#if !defined(SGEMM_EXP) || !(SGEMM_EXP & 4)
                         if (i * TN + j == 0 && kk + 2 < BK / 2) {        // fragments of the k pair after the next
 #pragma unroll
                             for (int ii = 0; ii < TM; ++ii) af[(kk + 2) % 3][ii] = a_s[(2 * (kk + 2)) * SA + ii * 32];
 #pragma unroll
                             for (int jj = 0; jj < TN; ++jj) bf[(kk + 2) % 3][jj] = b_s[(2 * (kk + 2)) * SB + jj * 32];
                         }
+#else
+                        if (i * TN + j == 0 && kk + 2 < BK / 2) {
+                            for (int ii = 0; ii < TM; ++ii) af[(kk + 2) % 3][ii] = af[kk % 3][ii];
+                            for (int jj = 0; jj < TN; ++jj) bf[(kk + 2) % 3][jj] = bf[kk % 3][jj];
+                        }
+#endif
+#if !defined(SGEMM_EXP) || !(SGEMM_EXP & 2)
 #pragma unroll
                         for (int u = 0; u < NL; ++u) {
                             const int gs = Q / 8 + (u * (3 * Q / 4)) / NL;               // store gap of unit u
                             if (q_ == gs) {
                                 if (u == 0) add_colsum();
-                                store_unit(u, cur ^ 1);                                  // tile kt+1 -> LDS
+#if defined(SGEMM_EXP) && (SGEMM_EXP & 8)
+                                if (u < NLA) asm volatile("" :: "v"(ra[u].x), "v"(ra[u].y), "v"(ra[u].z), "v"(ra[u].w));
+                                else asm volatile("" :: "v"(rb[u - NLA].x), "v"(rb[u - NLA].y), "v"(rb[u - NLA].z), "v"(rb[u - NLA].w));
+#else
+                                store_unit(u, CUR ^ 1);                                  // tile kt+1 -> LDS
+#endif
                             }
+#if !defined(SGEMM_EXP) || !(SGEMM_EXP & 16)
                             if (q_ == gs + 1) load_unit(u);                              // tile kt+2 -> registers
+#endif
                         }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+#if !defined(SGEMM_EXP) || !(SGEMM_EXP & 1)
             __syncthreads();
-            cur ^= 1;
+#endif
+        };
+        for (; kt + 2 < nfull; kt += 2) {           // cur == 0 here
+            tile_body(std::integral_constant<int, 0>(), true);
+            tile_body(std::integral_constant<int, 1>(), kt + 3 < nfull);
+        }
+        if (kt + 1 < nfull) {
+            tile_body(std::integral_constant<int, 0>(), false);
+            ++kt;
+            cur = 1;
         }
     }
     // ---- generic loop: edge blocks from tile 0; interior blocks only their last full tile and the K tail
@@ -440,7 +471,8 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
 }
 
 template <bool TA, bool TB>
-int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream) {
+int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, int* splits_out, int force_split,
+                  hipStream_t stream) {
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
     const int nkt = (a.K + BK - 1) / BK;
@@ -480,6 +512,10 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
         }
         if (S < 1) S = 1;
         if (S == 1) big = use_x || t128 >= 192;
+    }
+    if (force_split > 1 && a.ws != nullptr) {       // tail slab of a row-split problem: 128x128 tiles, K split as told
+        big = true;
+        S = force_split;
     }
     a.splitk = S;
     a.kper = ((nkt + S - 1) / S) * BK;
@@ -521,11 +557,60 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
 
 }   // namespace
 
+static int sgemm_dispatch(bool transA, bool transB, int M, int N, int K,
+                          const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, const float* bias, bool accumulate,
+                          float* colsum_a, bool colsum_accumulate,
+                          float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, int force_split, hipStream_t stream);
+
 int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
                            const float* A, int64_t lda, const float* B, int64_t ldb,
                            float* C, int64_t ldc, const float* bias, bool accumulate,
                            float* colsum_a, bool colsum_accumulate,
                            float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream) {
+    // Tail split.  A launch of t 128x128 tiles runs in ceil(t / 512) rounds of the chip's 512 resident block slots
+    // (2 per CU), and a short last round costs a whole one: the projection's dW product (391 x 8 = 3128 tiles = 6.1
+    // rounds) spent 1/7 of its time on 56 tiles.  With workspace at hand the rows are cut so that the first launch
+    // fills whole rounds and the remaining row tiles run as ONE more round with K split S ways (1/S as long),
+    // summed in a fixed order like every other split-K product here.
+    static const bool tail_on = []() { const char* e = getenv("LAED_GEMM_TAILSPLIT"); return !(e != nullptr && atoi(e) == 0); }();
+    if (tail_on && ws != nullptr && !raw_partials && M > 0 && N > 0 && K > 0 && A && B && C && !(transA && transB) &&
+        laed_get_gemm_mode() == 0) {
+        const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128, t = tm * tn;
+        const int nkt = (K + BK - 1) / BK;
+        if (t > 512 && nkt >= 16) {
+            const int64_t full = t / 512;
+            int64_t tm1 = full * 512 / tn;
+            if (tm1 > tm) tm1 = tm;
+            const int64_t tm2 = tm - tm1, t2 = tm2 * tn;
+            if (tm1 > 0 && tm2 > 0 && t2 <= 256) {
+                const int M1 = (int)(tm1 * 128), M2 = M - M1;
+                int64_t S = 512 / t2;
+                if (S > nkt / 8) S = nkt / 8;
+                const int64_t cap = ws_floats / ((int64_t)M2 * N + M2);
+                if (S > cap) S = cap;
+                if (S > 16) S = 16;
+                if (S >= 2) {
+                    if (splits_out) *splits_out = 1;
+                    LAED_TRY(sgemm_dispatch(transA, transB, M1, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, colsum_a,
+                                            colsum_accumulate, nullptr, 0, false, nullptr, 0, stream));
+                    const float* A2 = transA ? A + M1 : A + (int64_t)M1 * lda;
+                    return sgemm_dispatch(transA, transB, M2, N, K, A2, lda, B, ldb, C + (int64_t)M1 * ldc, ldc, bias, accumulate,
+                                          colsum_a ? colsum_a + M1 : nullptr, colsum_accumulate, ws, ws_floats, false, nullptr,
+                                          (int)S, stream);
+                }
+            }
+        }
+    }
+    return sgemm_dispatch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, colsum_a, colsum_accumulate,
+                          ws, ws_floats, raw_partials, splits_out, 0, stream);
+}
+
+static int sgemm_dispatch(bool transA, bool transB, int M, int N, int K,
+                          const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, const float* bias, bool accumulate,
+                          float* colsum_a, bool colsum_accumulate,
+                          float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, int force_split, hipStream_t stream) {
     LAED_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sgemm: negative dimension");
     if (splits_out) *splits_out = 1;
     if (M == 0 || N == 0) return 0;
@@ -543,9 +628,9 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
     a.tiles_m = a.tiles_n = 0;
     a.splitk = 1; a.kper = 0; a.ws = ws; a.ws_colsum = nullptr;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    if (!transA && transB) return launch_layout<false, true>(a, vec, ws_floats, raw_partials, splits_out, stream);
-    if (!transA && !transB) return launch_layout<false, false>(a, vec, ws_floats, raw_partials, splits_out, stream);
-    return launch_layout<true, false>(a, vec, ws_floats, raw_partials, splits_out, stream);
+    if (!transA && transB) return launch_layout<false, true>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
+    if (!transA && !transB) return launch_layout<false, false>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
+    return launch_layout<true, false>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
 }
 
 // NT product with row sums of A (bf16x3 mode only: the split-bf16 kernel sums its own A-operand registers).

@@ -22,7 +22,7 @@ def _f32c(t):
 # raw wrappers
 # ----------------------------------------------------------------------------------------------
 def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, colsum_out=None,
-          colsum_accumulate=False, splitk_ws=True):
+          colsum_accumulate=False, splitk_ws=True, ws_floats=0):
     """C = op(A) op(B) (+bias) (+C).  A, B 2-D fp32 (row stride arbitrary, unit column stride)."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -41,6 +41,9 @@ def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=Fals
     ws, ws_n = None, 0
     if splitk_ws and M * N <= (1 << 22) and K >= 2048:      # few output tiles, long K: let the library split K
         ws_n = 8 * (M * N + M)
+        ws = workspace("sgemm_ws", ws_n, A.device)
+    elif ws_floats > 0:                                     # caller-sized scratch (tail split of many-tile problems)
+        ws_n = int(ws_floats)
         ws = workspace("sgemm_ws", ws_n, A.device)
     check(lib.laed_sgemm_ws(int(transA), int(transB), M, N, K, vp(A), A.stride(0) if A.shape[0] > 1 else max(A.shape[1], 1),
                             vp(B), B.stride(0) if B.shape[0] > 1 else max(B.shape[1], 1),

@@ -81,6 +81,27 @@ def test_sgemm_splitk(ops, M, N, K):
         assert rel_err(Cd3.cpu(), ref) < 1e-5      # one K-long fp32 fma chain: more rounding than the split sum
 
 
+@pytest.mark.parametrize("M,N,K", [(4224, 2048, 512), (8500, 1024, 700), (4100, 2100, 1031)])
+def test_sgemm_tail_split(ops, M, N, K):
+    """More than one round of 128x128 tiles with a short last round: with workspace the library cuts the rows into a
+    whole-rounds launch plus a split-K launch for the remaining row tiles.  Same results as the single launch."""
+    for (tA, tB) in ((True, False), (False, True), (False, False)):
+        A = rnd(K, M, seed=1) if tA else rnd(M, K, seed=1)
+        B = rnd(N, K, seed=2) if tB else rnd(K, N, seed=2)
+        bias, C0 = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double() + bias.double() + C0.double()
+        Cd = dev(C0.clone())
+        cs = dev(torch.ones(M)) if tA else None
+        ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, bias=dev(bias), out=Cd, accumulate=True, colsum_out=cs,
+                  colsum_accumulate=True, ws_floats=16 * (256 * N + 256))
+        assert rel_err(Cd.cpu(), ref) < 2e-6, (tA, tB)
+        if tA:
+            assert rel_err(cs.cpu(), A.double().sum(0) + 1.0) < 2e-6
+        Cd2 = dev(C0.clone())
+        ops.sgemm(dev(A), dev(B), transA=tA, transB=tB, bias=dev(bias), out=Cd2, accumulate=True, splitk_ws=False)
+        assert rel_err(Cd2.cpu(), Cd.cpu().double()) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 2304, 200), (1536, 2100, 1024), (4000, 1111, 777), (2048, 2048, 4096)])
 def test_xgemm_bf16x3(ops, M, N, K):
     """Opt-in split-bf16 math mode for x W^T: fp32-grade results (error within ~10x of the exact-fp32 kernel)."""
