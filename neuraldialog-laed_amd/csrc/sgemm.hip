@@ -134,14 +134,17 @@ __device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const
 }
 
 template <int BM, int BN, bool TA, bool TB, bool VEC, int NT>
-__global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmArgs p) {
     constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
     constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
     constexpr int SA = BM + (AK ? 1 : 4);
     constexpr int SB = BN + (BKC ? 1 : 4);
-    // waves form a 2 x WGN grid over the block tile (WGN = 2 for 256 threads, 4 for 512); wave tile (BM/2) x (BN/WGN)
-    constexpr int WGN = NT / 128;
-    constexpr int TM = BM / 64, TN = BN / WGN / 32;
+    // waves form a WGM x WGN grid over the block tile: 2 x 2 (256 threads), 2 x 4 (512); wave tile (BM/WGM) x (BN/WGN).
+    // (4 x 4 = 1024 threads on a 256x256 tile, one block per CU, was measured: 137.6 vs 135.4 TFLOP/s at 8192^3 but
+    // slower on every projection shape once their tile counts are counted in rounds of 256 slots -- not kept.)
+    constexpr int WGM = NT >= 1024 ? 4 : 2;
+    constexpr int WGN = NT / 64 / WGM;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int NLA = BM * BK / 4 / NT, NLB = BN * BK / 4 / NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                 // [2][BK][SA]
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
     const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
     const int lrow = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    const float* a_base = sA + wm * (BM / 2) + lrow + lk * SA;   // fragment row (2*kk + lk) folded into the base
+    const float* a_base = sA + wm * (BM / WGM) + lrow + lk * SA;   // fragment row (2*kk + lk) folded into the base
     const float* b_base = sB + wn * (BN / WGN) + lrow + lk * SB;
 
     auto add_colsum = [&]() {
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(SgemmArgs p) {
             const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                const int row = m0 + wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (row < p.M && col < p.N) {
                     if (p.splitk > 1) {
                         p.ws[((int64_t)split * p.M + row) * p.N + col] = acc[i][j][e];
