@@ -141,7 +141,11 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmAr
     constexpr int SB = BN + (BKC ? 1 : 4);
     // waves form a WGM x WGN grid over the block tile: 2 x 2 (256 threads), 2 x 4 (512); wave tile (BM/WGM) x (BN/WGN).
     // (4 x 4 = 1024 threads on a 256x256 tile, one block per CU, was measured: 137.6 vs 135.4 TFLOP/s at 8192^3 but
-    // slower on every projection shape once their tile counts are counted in rounds of 256 slots -- not kept.)
+    // slower on every projection shape once their tile counts are counted in rounds of 256 slots -- not kept.
+    // LDS-DMA staging (global_load_lds_dwordx4 into lane-linear images, XOR-swizzled quads read with ds_read_b128 and
+    // a permuted k order; 12 DS + 4 VMEM instead of 40 DS + 27 VALU + 4 VMEM per K tile) was built and measured too:
+    // 132.4 vs 135.3 TFLOP/s at 8192^3 -- two LDS buffers force the DMA of tile t+1 into tile t, and the one-tile
+    // prefetch distance of the register path below is worth more than the instructions saved -- not kept.)
     constexpr int WGM = NT >= 1024 ? 4 : 2;
     constexpr int WGN = NT / 64 / WGM;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmAr
     float* sA = smem;                 // [2][BK][SA]
     float* sB = smem + 2 * BK * SA;   // [2][BK][SB]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: keep it (and wm, wn) in SGPRs
     const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware remap (bijective for any grid size), then grouped ordering over row tiles
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmAr
 
     auto add_colsum = [&]() {
         if (TA && do_colsum) {
+            asm volatile("; colsum" ::: "memory");     // keeps this a (scalar) branch: 7 of 8 blocks skip the adds
 #pragma unroll
             for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
         }
