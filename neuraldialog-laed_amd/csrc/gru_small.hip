@@ -221,6 +221,259 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
     p.dx_out[((int64_t)((2 * H + j) / 4) * BP + row) * 4 + e4] = dnr;
 }
 
+// ---- persistent forward: ALL T steps in one launch, the workgroup's W_hh slab resident in LDS across timesteps.
+// Workgroups exchange h_t through the quad-major ping-pong buffers inside the launch:
+//   producer: write-through (sc1) stores of its slice -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane
+//             adds 1 to an agent-scope arrival counter;
+//   consumer: one lane polls the counter (sc1 loads, s_sleep, BOUNDED: on timeout it raises sync[1] and the workgroup
+//             stops waiting, so the grid always drains) -> workgroup barrier -> sc1 buffer loads of h_{t-1}.
+// (MI355X_MICROARCH.md, inter-workgroup visibility, "valid forms" table row 3: each 128-byte line of the payload is
+// written whole by one store instruction of one wave; one workgroup per CU, forced by the LDS request.)
+// h_{t-1} of a workgroup's own units stays in registers.  Needs all H/UF workgroups resident at once (H/UF <= 256).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int WS4 = 16;             // float4 slots per quad in the LDS slab (12 used: keeps the kq groups on disjoint banks)
+constexpr unsigned SPIN_LIMIT = 4000000;    // ~4 s of polling: only a grid that can never become resident gets there
+
+template <int RT, int NC, int WS>
+__device__ __forceinline__ void persist_core(__amdgpu_buffer_rsrc_t x, const float* __restrict__ slab, int ngrp, int wave, int lane,
+                                             f32x4 (&acc)[RT]) {
+    constexpr int BP = 16 * RT;
+    const int li = lane & 15, kq = lane >> 4;
+    const bool bval = li < NC;
+    const int q0 = wave * 4 * ngrp + kq;
+    const int aoff = (q0 * BP + li) * 16;                                        // bytes
+    const float4* bp = reinterpret_cast<const float4*>(slab) + q0 * WS + (bval ? li : 0);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g0 = 0; g0 < ngrp; g0 += CH) {
+        u32x4 a[CH][RT];
+        float4 b[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int g = g0 + c;
+            if (g < ngrp) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[c][rt] = __builtin_amdgcn_raw_buffer_load_b128(x, aoff + (4 * g * BP + rt * 16) * 16, 0, 16);
+                b[c] = bval ? bp[4 * g * WS] : z4;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (g0 + c < ngrp) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[c][rt].x), b[c].x, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[c][rt].y), b[c].y, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[c][rt].z), b[c].z, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[c][rt].w), b[c].w, acc[rt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+struct PersistFwdArgs {
+    float* hx0;             // [H/4][BP][4]: h0 on entry (quad-major); ping
+    float* hx1;             //               pong
+    const float* wp;        // [H/UF][H/4][3 UF][4] packed W_hh
+    const float* b_hh;
+    float* hbuf;            // [(T+1)][B][H], hbuf[0] = h0
+    float* gates;           // [T][B][3H]
+    float* hn;              // [T][B][H] or NULL
+    unsigned* sync;         // [0] arrival counter, [1] timeout flag; zeroed before the launch
+    int T, B, H, nkw;
+};
+
+template <int RT>
+__global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdArgs p) {
+    constexpr int NC = 3 * UF, BP = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, B = p.B, j0 = blockIdx.x * UF;
+    float* slab = lds;                               // [H/4][WS4][4]
+    float* red = lds + (int64_t)H * WS4;             // [NW][BP][NC]
+    {   // the workgroup's W_hh slab: HBM/L2 -> LDS once for all T steps
+        const float4* src = reinterpret_cast<const float4*>(p.wp + (int64_t)blockIdx.x * H * NC);
+        for (int i = tid; i < (H / 4) * NC; i += NTH) reinterpret_cast<float4*>(slab)[(i / NC) * WS4 + i % NC] = src[i];
+    }
+    const int row = tid / UF, u = tid % UF, j = j0 + u;
+    const bool mine = row < B;
+    float hp = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f;
+    if (mine) {
+        hp = p.hbuf[(int64_t)row * H + j];
+        bhr = p.b_hh[j]; bhz = p.b_hh[H + j]; bhn = p.b_hh[2 * H + j];
+    }
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(p.hx0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(p.hx1, 0, 0x7fffffff, 0x00020000);
+    const unsigned G = gridDim.x;
+    bool dead = false;                               // set (per workgroup, via LDS) once a wait has timed out
+    __shared__ unsigned s_dead;
+    if (tid == 0) s_dead = 0;
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+        float* g = p.gates + ((int64_t)t * B + row) * 3 * H;
+        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+        if (mine) { gi_r = g[j]; gi_z = g[H + j]; gi_n = g[2 * H + j]; }
+        if (t > 0) {                                 // every workgroup's slice of h_{t-1} must have been published
+            if (tid == 0 && !dead) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)t) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > SPIN_LIMIT) {
+                        __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            dead = s_dead != 0;
+        }
+        if (wave < p.nkw) {
+            f32x4 acc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
+            persist_core<RT, NC, WS4>((t & 1) ? rx1 : rx0, slab, H / 16 / p.nkw, wave, lane, acc);
+            spill_partials<RT, NC>(red, acc, wave, lane);
+        }
+        __syncthreads();
+        if (row < BP) {
+            float h = 0.f;
+            if (mine) {
+                const float ghr = sum_partials<RT, NC>(red, p.nkw, row, u), ghz = sum_partials<RT, NC>(red, p.nkw, row, UF + u);
+                const float ghn = sum_partials<RT, NC>(red, p.nkw, row, 2 * UF + u) + bhn;
+                const float r = sigmoidf_acc(gi_r + ghr + bhr);
+                const float z = sigmoidf_acc(gi_z + ghz + bhz);
+                const float n = tanhf(gi_n + r * ghn);
+                h = (1.0f - z) * n + z * hp;
+                if (dead) h = __builtin_nanf("");         // a timed-out wait poisons the output: loud, not silently stale
+                hp = h;
+                p.hbuf[((int64_t)(t + 1) * B + row) * H + j] = h;
+                if (p.hn != nullptr) {
+                    g[j] = r; g[H + j] = z; g[2 * H + j] = n;
+                    p.hn[((int64_t)t * B + row) * H + j] = ghn;
+                }
+            }
+            float* hx_out = (t & 1) ? p.hx0 : p.hx1;
+            __hip_atomic_store(hx_out + ((int64_t)(j / 4) * BP + row) * 4 + (j & 3), h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores ...
+        __syncthreads();                                           // ... before one lane signals for the workgroup
+        if (tid == 0) __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- persistent backward: the whole reverse recurrence in one launch, the workgroup's W_hh^T slab resident in LDS.
+// Same hand-off as the forward kernel; step s = T-1-t publishes dgh_t (quad-major, sc1) and step s+1 consumes it.
+// The dh carry of a workgroup's own (row, unit) pairs stays in registers.  Step s = T has no gate math: it only
+// forms dh_0 = carry + dgh_0 W_hh.
+struct PersistBwdArgs {
+    float* dx0;              // [3H/4][BP][4] ping
+    float* dx1;              //               pong
+    const float* wpT;        // [H/UB][3H/4][UB][4] packed W_hh^T
+    const float* dout;       // [T][B][H] or NULL
+    const float* hbuf;       // [(T+1)][B][H]
+    const float* hn;         // [T][B][H]
+    float* gates;            // [T][B][3H] in: r,z,n  out: d(gi)
+    float* dgh;              // [T][B][3H] out
+    float* dh;               // [B][H] in: dh_T, out: dh_0
+    unsigned* sync;          // [0] arrival counter, [1] timeout flag; zeroed before the launch
+    int T, B, H, nkw;
+};
+
+template <int RT>
+__global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdArgs p) {
+    constexpr int NC = UB, BP = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, B = p.B, j0 = blockIdx.x * UB, K = 3 * H;
+    float* slab = lds;                               // [3H/4][UB][4]
+    float* red = lds + (int64_t)K * NC;              // [NW][BP][NC]
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.wpT + (int64_t)blockIdx.x * K * NC);
+        for (int i = tid; i < (K / 4) * NC; i += NTH) reinterpret_cast<float4*>(slab)[i] = src[i];
+    }
+    const int row = tid / UB, u = tid % UB, j = j0 + u;
+    const bool mine = row < B;
+    const int64_t i = (int64_t)row * H + j;
+    float carry = mine ? p.dh[i] : 0.f;
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(p.dx0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(p.dx1, 0, 0x7fffffff, 0x00020000);
+    const unsigned G = gridDim.x;
+    bool dead = false;
+    __shared__ unsigned s_dead;
+    if (tid == 0) s_dead = 0;
+    __syncthreads();
+    for (int s = 0; s <= p.T; ++s) {
+        const int t = p.T - 1 - s;                   // t = -1: the closing step
+        const bool fin = t < 0;
+        float dh = carry, r = 0.f, z = 0.f, nn = 0.f, hnv = 0.f, hp = 0.f;
+        float* g = fin ? nullptr : p.gates + ((int64_t)t * B + row) * 3 * H;
+        if (mine && !fin) {
+            const int64_t it = (int64_t)t * B * H + i;
+            if (p.dout != nullptr) dh += p.dout[it];
+            r = g[j]; z = g[H + j]; nn = g[2 * H + j];
+            hnv = p.hn[it]; hp = p.hbuf[it];
+        }
+        if (s > 0) {                                 // every workgroup's slice of dgh_{t+1} must have been published
+            if (tid == 0 && !dead) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)s) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > SPIN_LIMIT) {
+                        __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_dead = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            dead = s_dead != 0;
+            if (wave < p.nkw) {
+                f32x4 acc[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
+                persist_core<RT, NC, UB>((s & 1) ? rx0 : rx1, slab, K / 16 / p.nkw, wave, lane, acc);     // step s-1 wrote dx[(s-1)&1]
+                spill_partials<RT, NC>(red, acc, wave, lane);
+            }
+            __syncthreads();
+            if (mine) dh += sum_partials<RT, NC>(red, p.nkw, row, u);
+        }
+        if (dead) dh = __builtin_nanf("");
+        if (fin) {
+            if (mine) p.dh[i] = dh;
+            break;
+        }
+        if (row < BP) {
+            float drp = 0.f, dzp = 0.f, dnr = 0.f;
+            if (mine) {
+                float* d = p.dgh + ((int64_t)t * B + row) * 3 * H;
+                const float dn = dh * (1.0f - z);
+                const float dz = dh * (hp - nn);
+                const float dnp = dn * (1.0f - nn * nn);
+                dzp = dz * z * (1.0f - z);
+                drp = dnp * hnv * r * (1.0f - r);
+                dnr = dnp * r;
+                g[j] = drp; g[H + j] = dzp; g[2 * H + j] = dnp;
+                d[j] = drp; d[H + j] = dzp; d[2 * H + j] = dnr;
+                carry = dh * z;
+            }
+            float* dx_out = (s & 1) ? p.dx1 : p.dx0;
+            const int e4 = j & 3;
+            __hip_atomic_store(dx_out + ((int64_t)(j / 4) * BP + row) * 4 + e4, drp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dx_out + ((int64_t)((H + j) / 4) * BP + row) * 4 + e4, dzp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dx_out + ((int64_t)((2 * H + j) / 4) * BP + row) * 4 + e4, dnr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // wp[wg][q][c][e] = W_hh[(c / UF) H + wg UF + c % UF][4q + e]      (one float4 per thread)
 __global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wp) {
     constexpr int NC = 3 * UF;
@@ -294,8 +547,8 @@ bool laed_gru_small_ok(int B, int H) {
 
 int laed_gru_small_bp(int B) { return (B + 15) / 16 * 16; }
 
-int64_t laed_gru_small_fwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * H * laed_gru_small_bp(B); }
-int64_t laed_gru_small_bwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * 3 * H * laed_gru_small_bp(B); }
+int64_t laed_gru_small_fwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * H * laed_gru_small_bp(B) + 64; }
+int64_t laed_gru_small_bwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * 3 * H * laed_gru_small_bp(B) + 64; }
 
 // forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
 int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
@@ -308,6 +561,34 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
     LAED_LAUNCH_CHECK("gru_small pack_w_fwd");
     hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, hx[0]);
     LAED_LAUNCH_CHECK("gru_small rows_to_quads");
+    // default: one persistent launch with LDS-resident W_hh (4.9 vs 6.3 us per step + launch gaps at B = 30, H = 512);
+    // LAED_GRU_PERSIST=0 selects the per-step launches below
+    static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
+    if (persist && H / UF <= 256) {
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP);
+        hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
+        if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
+        PersistFwdArgs a;
+        a.hx0 = hx[0]; a.hx1 = hx[1]; a.wp = wp; a.b_hh = b_hh; a.hbuf = hbuf; a.gates = gates; a.hn = hn; a.sync = sync;
+        a.T = T; a.B = B; a.H = H; a.nkw = k_waves(H);
+        size_t lds = ((size_t)H * WS4 + (size_t)NW * BP * 3 * UF) * sizeof(float);
+        if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU (160 KB LDS per CU)
+        if (lds > 160 * 1024) return laed_fail(LAED_E_SIZE, "gru_small: LDS slab too large (H = %d)", H);
+        auto go = [&](auto kern) -> int {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e2 != hipSuccess) return laed_fail((int)e2, "gru_small: hipFuncSetAttribute failed");
+            hipLaunchKernelGGL(kern, dim3(H / UF), dim3(NTH), lds, stream, a);
+            return 0;
+        };
+        int st;
+        if (B <= 16) st = go(gru_small_persist_fwd_kernel<1>);
+        else if (B <= 32) st = go(gru_small_persist_fwd_kernel<2>);
+        else if (B <= 48) st = go(gru_small_persist_fwd_kernel<3>);
+        else st = go(gru_small_persist_fwd_kernel<4>);
+        if (st != 0) return st;
+        LAED_LAUNCH_CHECK("gru_small_persist_fwd");
+        return 0;
+    }
     for (int t = 0; t < T; ++t) {
         SmallFwdArgs a;
         a.hx_in = hx[t & 1]; a.wp = wp; a.b_hh = b_hh; a.hprev = hbuf + (int64_t)t * BH;
@@ -331,6 +612,33 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
     float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP};
     hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT);
     LAED_LAUNCH_CHECK("gru_small pack_w_bwd");
+    static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
+    if (persist && H / UB <= 256) {
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * BP);
+        hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
+        if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
+        PersistBwdArgs a;
+        a.dx0 = dx[0]; a.dx1 = dx[1]; a.wpT = wpT; a.dout = dout; a.hbuf = hbuf; a.hn = hn; a.gates = gates; a.dgh = dgh;
+        a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H);
+        size_t lds = ((size_t)3 * H * UB + (size_t)NW * BP * UB) * sizeof(float);
+        if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU
+        if (lds <= 160 * 1024) {
+            auto go = [&](auto kern) -> int {
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e2 != hipSuccess) return laed_fail((int)e2, "gru_small: hipFuncSetAttribute failed");
+                hipLaunchKernelGGL(kern, dim3(H / UB), dim3(NTH), lds, stream, a);
+                return 0;
+            };
+            int st;
+            if (B <= 16) st = go(gru_small_persist_bwd_kernel<1>);
+            else if (B <= 32) st = go(gru_small_persist_bwd_kernel<2>);
+            else if (B <= 48) st = go(gru_small_persist_bwd_kernel<3>);
+            else st = go(gru_small_persist_bwd_kernel<4>);
+            if (st != 0) return st;
+            LAED_LAUNCH_CHECK("gru_small_persist_bwd");
+            return 0;
+        }
+    }
     for (int t = T - 1; t >= -1; --t) {
         SmallBwdArgs a;
         const bool fin = t < 0;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): every measurement profiles/ is built from, into gpurun_out/final/.
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
+# then, back in the build container:  python tools/publish_profiles.py r1
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/final
+rm -rf $O && mkdir -p $O
+step() { echo "== $*" >> $O/steps.log; "$@"; rc=$?; echo "rc=$rc" >> $O/steps.log; if [ $rc -ne 0 ]; then echo "FAILED: $*"; exit $rc; fi; }
+# 1. bench lines (default run = the driver's command; then the other workloads)
+step timeout -k 10 500 python bench.py > $O/bench_S-fixed.json 2> $O/bench_S-fixed.err
+step timeout -k 10 200 python bench.py --global-batch 512 --no-alt --cpu-sample 0 > $O/bench_S-fixed_b512.json 2>> $O/bench.err
+for w in P-fixed P-varlen VST-fixed; do
+  step timeout -k 10 200 python bench.py --workload $w --steps 50 --warmup 10 --no-alt > $O/bench_$w.json 2>> $O/bench.err
+done
+# 2. rocprofv3 kernel stats of the S-fixed step (same command line as the live-roofline line it is compared with)
+step timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_S-fixed -- python bench.py --steps 3 --warmup 1 --no-alt --cpu-sample 0 > $O/prof_S-fixed.json 2> $O/prof_S-fixed.err
+for w in P-fixed VST-fixed; do
+  step timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python bench.py --workload $w --steps 20 --warmup 5 --no-alt --cpu-sample 0 > $O/prof_$w.json 2> $O/prof_$w.err
+done
+# 3. PMC passes, one counter block per run
+step timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_fetch.log 2>&1
+step timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_write.log 2>&1
+step timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_mfma.log 2>&1
+rm -f $O/*/*/*kernel_trace.csv        # large; the stats CSV is what profiles/ keeps
+echo done
