@@ -1,0 +1,137 @@
+"""Full-size checks at the headline shape (BASELINE.json config 5 / SURVEY.md 8d "S-fixed": V=50000, E=200, H=1024,
+y=20, k=10, T=40, B=4096).  The oracle cannot run 4096 sequences in seconds, so parity at this size is taken through
+what the domain offers:
+  * sequences are independent through encoder, latent, decoder and per-token NLL (given the injected Gumbel noise),
+    so a SUBSET of the full batch must match the oracle run on that subset alone: log q(y|x), latent ids, decoder
+    initial state and every per-token NLL, at the north-star tolerance (1e-4 relative; ids exact);
+  * the 'word' NLL is the non-PAD mean of the per-token NLLs of the whole batch, and BPR / KL / MI follow from the
+    full log q(y|x) tensor by the oracle's own formula (cheap on the CPU: [B*y, k]);
+  * a training step is deterministic: two runs from the same state give bitwise-equal losses and (atomic-free)
+    gradients; every row of the softmax-CE gradient sums to zero, so the projection bias gradient sums to ~0.
+"""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+V, E, H, Y, K, T, B = 50000, 200, 1024, 20, 10, 40, 4096
+
+
+def _config():
+    return Namespace(embed_size=E, max_utt_len=T, num_layer=1, dropout=0.3, enc_cell_size=H, dec_cell_size=H,
+                     rnn_cell='gru', max_dec_len=T, use_attn=False, beam_size=10, utt_type='rnn', bi_enc_cell=False,
+                     attn_type='cat', fix_batch=False, y_size=Y, k=K, use_gpu=True, avg_type='word',
+                     use_mutual=True, use_reg_kl=True, train_prior=False, init_lr=0.001, op='adam', batch_size=B)
+
+
+class _Corpus(object):
+    vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
+    rev_vocab = {w: i for i, w in enumerate(vocab)}
+
+
+def _batch(seed=1234):
+    """Zipf interior ids as bench.py's S-fixed batch, with ragged PAD tails on a quarter of the rows."""
+    rs = np.random.RandomState(seed)
+    p = 1.0 / np.arange(1, V - 4 + 1, dtype=np.float64)
+    p /= p.sum()
+    out = np.empty((B, T), dtype=np.int32)
+    out[:, 0] = 2
+    out[:, 1:T - 1] = 4 + rs.choice(V - 4, size=(B, T - 2), p=p)
+    out[:, T - 1] = 3
+    for b in range(0, B, 4):                      # shorter sequences: </s> then PAD (ids 0)
+        L = int(rs.randint(3, T))
+        out[b, L - 1] = 3
+        out[b, L:] = 0
+    return out
+
+
+@pytest.fixture(scope="module")
+def model():
+    from laed_amd.models.sent_models import DiVAE
+    torch.manual_seed(0)
+    m = DiVAE(_Corpus(), _config()).cuda()
+    return m
+
+
+def test_subset_of_full_batch_matches_oracle(model):
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from oracle import laed_oracle as O
+    batch = _batch()
+    rs = np.random.RandomState(5)
+    u = rs.uniform(size=(B * Y, K)).astype(np.float32)
+    ud = torch.from_numpy(u).cuda()
+    model.cat_connector.sample_uniform = lambda logits: ud
+    model.eval()                                   # no dropout; hard one-hot latent from logits + injected noise
+    with torch.no_grad():
+        res = model({"outputs": batch, "output_lens": [T] * B}, mode=TEACH_FORCE, return_latent=True)
+    tok = model.nll_loss_tok()                     # [B, T-1]
+    log_qy = res.log_qy.detach().cpu().view(B, Y, K)
+    # (1) whole-batch reductions from the per-row outputs
+    labels = batch[:, 1:]
+    cnt = int((labels != 0).sum())
+    assert abs(float(res.nll) - float(tok.sum(dtype=np.float64)) / cnt) <= 1e-5 * abs(float(res.nll))
+    assert float(np.abs(tok[labels == 0]).max()) == 0.0
+    reg_kl, bpr, mi = O.latent_losses(log_qy.view(-1, K), Y, K, True)
+    assert abs(float(res.bpr) - float(bpr)) <= 1e-7 + 1e-4 * abs(float(bpr))
+    assert abs(float(res.reg_kl) - float(reg_kl)) <= 1e-7 + 1e-4 * abs(float(reg_kl))
+    assert abs(float(res.mi) - float(mi)) <= 1e-6 + 5e-3 * abs(float(mi))
+    # (2) a subset of the sequences against the oracle run on that subset alone
+    sel = np.concatenate([np.arange(0, 8), np.array([1023, 1024, 2048, 2051, 4088, 4095])])      # incl. ragged rows
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    P["decoder.embedding.weight"] = P["embedding.weight"]
+    usel = u.reshape(B, Y, K)[sel].reshape(-1, K)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = O.divae_forward(P, _config(), batch[sel], usel, training=False)
+    assert np.array_equal(res.y_ids.detach().cpu().numpy()[sel], ref["y_ids"].numpy())
+    a, b = log_qy[sel].reshape(-1, K).numpy(), ref["log_qy"].detach().numpy()
+    assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(b))
+    a, b = res.dec_init_state.detach().cpu().numpy()[0][sel], ref["dec_init_state"].detach().numpy()[0]
+    assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(b))
+    mask = labels[sel] != 0
+    a, b = tok[sel][mask], ref["tok_nll"].detach().numpy()[mask]
+    assert np.max(np.abs(a - b) / np.abs(b)) <= 1e-4, float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def test_training_step_is_deterministic_and_ce_gradient_rows_sum_to_zero(model):
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    batch = _batch(seed=99)
+    rs = np.random.RandomState(6)
+    ud = torch.from_numpy(rs.uniform(size=(B * Y, K)).astype(np.float32)).cuda()
+    model.cat_connector.sample_uniform = lambda logits: ud
+    model.train()
+    keep = torch.from_numpy((rs.uniform(size=(B, T - 1, E)) >= 0.3).astype(np.uint8)).cuda()
+    runs = []
+    for _ in range(2):
+        model.decoder.injected_keep = keep
+        for p in model.parameters():
+            p.grad = None
+        loss = model({"outputs": batch, "output_lens": [T] * B}, mode=TEACH_FORCE)
+        model.backward(0, loss)
+        torch.cuda.synchronize()
+        runs.append((float(loss.nll.detach()), float(loss.reg_kl.detach()),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    for n in runs[0][2]:
+        if n == "embedding.weight":      # fp32 atomics in the scatter-add: order-dependent rounding only
+            a, b = runs[0][2][n], runs[1][2][n]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        else:
+            assert torch.equal(runs[0][2][n], runs[1][2][n]), n
+    g = runs[0][2]
+    db = g["decoder.project.bias"].double()
+    # each row of (softmax - onehot) * scale sums to 0, so sum_v db[v] = 0 up to fp32 rounding of 50000 column sums
+    assert abs(float(db.sum())) <= 1e-4 * float(db.abs().sum())
+    assert float(g["embedding.weight"][0].abs().max()) == 0.0          # PAD row gets no gradient
+    for n, t in g.items():
+        assert bool(torch.isfinite(t).all()), n
