@@ -14,7 +14,6 @@
 
 namespace {
 
-constexpr int BK = 32;
 
 struct GruStepArgs {
     const float* hprev;   // [B][H]
@@ -26,14 +25,16 @@ struct GruStepArgs {
     int B, H;
 };
 
-// WM row tiles x WK K-splits, WM*WK == 4 waves
-template <int WM, int WK, bool VEC>
-__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
+// WM row tiles x WK K-splits = NT/64 waves (4 waves with K tiles of 32, or 8 waves with K tiles of 64: in both a load
+// pass covers 32 rows, i.e. the h tile in WM passes and one gate block of the W tile per pass)
+template <int WM, int WK, bool VEC, int NT = 256, int BK = 32>
+__global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
+    static_assert(WM * WK * 64 == NT && NT / (BK / 4) == 32, "geometry");
     constexpr int BR = 32 * WM;        // batch rows per block
     constexpr int SH = BR + 1;         // K-contiguous operands: transposing b32 writes, pad 1
     constexpr int SW = 96 + 1;
-    constexpr int NLH = BR * BK / 4 / 256 > 0 ? BR * BK / 4 / 256 : 1;   // float4 per thread (h tile)
-    constexpr int NLW = 96 * BK / 4 / 256;                               // = 3
+    constexpr int NLH = BR * BK / 4 / NT > 0 ? BR * BK / 4 / NT : 1;   // float4 per thread (h tile)
+    constexpr int NLW = 96 * BK / 4 / NT;                                // = 3
     constexpr int TILE = BK * (SH + SW);
     constexpr int RED = (WK > 1) ? (WK - 1) * WM * 64 * 48 : 0;
     constexpr int SMEM = (2 * TILE > RED) ? 2 * TILE : RED;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
     auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NLH; ++i) {
-            int idx = tid + i * 256;
+            int idx = tid + i * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < BR * BK / 4) {
                 int row = idx / (BK / 4), kq = idx % (BK / 4);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
-            int idx = tid + i * 256;
+            int idx = tid + i * NT;
             int row = idx / (BK / 4), kq = idx % (BK / 4);   // row in [0,96): gate = row/32, unit = row%32
             int unit = j0 + (row & 31), gk = k0 + 4 * kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
         float* dw = sW + buf * BK * SW;
 #pragma unroll
         for (int i = 0; i < NLH; ++i) {
-            int idx = tid + i * 256;
+            int idx = tid + i * NT;
             if (idx < BR * BK / 4) {
                 int row = idx / (BK / 4), kq = idx % (BK / 4);
                 float* d = dh + (4 * kq) * SH + row;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
-            int idx = tid + i * 256;
+            int idx = tid + i * NT;
             int row = idx / (BK / 4), kq = idx % (BK / 4);
             float* d = dw + (4 * kq) * SW + row;
             d[0] = rw[i].x; d[SW] = rw[i].y; d[2 * SW] = rw[i].z; d[3 * SW] = rw[i].w;
@@ -143,12 +144,19 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
     }
     __syncthreads();
     int cur = 0, kt = 0;
-    if (fast) {
+    if (fast && nfull >= 2) {
+        // prefetch distance = one whole K tile (as in sgemm.hip): while tile kt multiplies out of LDS[cur], the registers
+        // (tile kt+1, fetched during tile kt-1) go to LDS[cur^1] and are refilled with tile kt+2 unit by unit, so a
+        // load has a full tile of MFMA time to land -- with one block per CU (B = 512) the half-tile distance used
+        // before stalled every K tile on vmcnt.  The last pass re-reads tile kt+1 (cache hit, unused) instead of branching.
+        gh += BK;
+        gw += BK;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) load_unit(u);
         for (; kt + 1 < nfull; ++kt) {
             const float* h_s = sH + cur * BK * SH + wm * 32 + lrow + (2 * wq + lk) * SH;
             const float* w_s = sW + cur * BK * SW + lrow + (2 * wq + lk) * SW;
-            gh += BK;
-            gw += BK;
+            if (kt + 2 < nfull) { gh += BK; gw += BK; }
             float af[2], bf[2][3];
             af[0] = h_s[0];
             bf[0][0] = w_s[0]; bf[0][1] = w_s[32]; bf[0][2] = w_s[64];
@@ -165,8 +173,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
                     }
 #pragma unroll
                     for (int u = 0; u < NL; ++u) {
-                        if (q_ == (u * (Q / 4)) / NL) load_unit(u);
-                        if (q_ == (Q >= 32 ? Q / 2 + (u * (Q / 4)) / NL : (Q - NL + u > 0 ? Q - NL + u : 0))) store_unit(u, cur ^ 1);
+                        const int gs = Q / 8 + (u * (3 * Q / 4)) / NL;      // store gap of unit u
+                        if (q_ == gs) store_unit(u, cur ^ 1);               // tile kt+1 -> LDS
+                        if (q_ == gs + 1) load_unit(u);                     // tile kt+2 -> registers
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -239,11 +248,11 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepArgs p) {
     }
 }
 
-template <int WM, int WK>
+template <int WM, int WK, int NT = 256, int BKT = 32>
 int launch_step(const GruStepArgs& a, bool vec, hipStream_t stream) {
     dim3 grid((a.B + 32 * WM - 1) / (32 * WM), (a.H + 31) / 32);
-    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false>), grid, dim3(256), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true, NT, BKT>), grid, dim3(NT), 0, stream, a);
+    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false, NT, BKT>), grid, dim3(NT), 0, stream, a);
     LAED_LAUNCH_CHECK("gru_step_fwd");
     return 0;
 }
@@ -256,6 +265,7 @@ int gru_step(const GruStepArgs& a, hipStream_t stream) {
     if (forced_wm == 4) return launch_step<4, 1>(a, vec, stream);
     if (forced_wm == 2) return launch_step<2, 2>(a, vec, stream);
     if (forced_wm == 1) return launch_step<1, 4>(a, vec, stream);
+    if (forced_wm == 8) return launch_step<2, 4, 512, 64>(a, vec, stream);
     // measured at H = 1024 (tools/gru_geom.py, us/step incl. the input GEMM share, B = 256 / 512 / 2048 / 4096):
     //   128-row tiles 92 / 98 / 173 / 333,  64-row tiles 51 / 56 / 161 / 309,  32-row tiles (K split 4 ways) 39 / 70 / 256 / -
     // 64-row tiles (41 KB of LDS: three blocks = 12 waves per CU) win from one block per CU upwards; smaller batches

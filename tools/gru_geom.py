@@ -4,7 +4,7 @@ import torch
 from laed_amd import ops
 from bench_kernels import timeit
 H, E = 1024, 200
-for B in (256, 512, 4096):
+for B in (256, 512, 1024, 2048, 4096):
     T = 8
     x = torch.randn(T, B, E, device="cuda")
     w_ih, w_hh = torch.randn(3 * H, E, device="cuda") * 0.03, torch.randn(3 * H, H, device="cuda") * 0.03
