@@ -19,6 +19,7 @@ bounded sample of the same workload.
 import argparse
 import ctypes
 import json
+import gc
 import os
 import sys
 import time
@@ -216,11 +217,21 @@ def main():
     def measure(mode):
         """warm-up + timed steps in one GEMM math mode -> dict (rank 0 fills the derived fields)."""
         _ops.set_gemm_mode(mode)
-        for _ in range(args.warmup):
-            step()
-        fence()
         prof = not args.no_prof
-        if prof:
+        prof_out = (ctypes.c_double * 21)()
+        for i in range(args.warmup):
+            if prof and i == args.warmup - 1:               # count one step's GEMM launches ...
+                fence()
+                lib.laed_prof_enable(1)
+            step()
+        gc.collect()
+        gc.freeze()     # the model / vocabulary objects are long-lived: keep full collections (25-30 ms of host stall,
+        fence()         # a tenth of a 50-step P-fixed run) from walking them inside the timed region
+        if prof:                                            # ... and create the timed region's events before it starts
+            lib.laed_prof_enable(0)
+            lib.laed_prof_collect(prof_out)
+            per_step_launches = int(sum(prof_out[v * 3] for v in range(7))) if args.warmup > 0 else 4096
+            lib.laed_prof_reserve(2 * per_step_launches * args.steps + 64)
             lib.laed_prof_enable(1)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
@@ -230,8 +241,10 @@ def main():
             marks[i + 1].record()                           # device-side per-step spread (no host sync inside the loop)
         fence()
         elapsed = time.perf_counter() - t0
-        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-        prof_out = (ctypes.c_double * 21)()
+        raw_steps = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        if os.environ.get("LAED_BENCH_DEBUG"):
+            print("per-step device ms:", " ".join("%.2f" % x for x in raw_steps), file=sys.stderr)
+        per_step = sorted(raw_steps)
         if prof:
             lib.laed_prof_enable(0)
             lib.laed_prof_collect(prof_out)
@@ -276,7 +289,8 @@ def main():
                 "fwd_bwd_ms": round(fwd_bwd_ms, 3),
                 "step_ms_device": {"median": round(per_step[len(per_step) // 2], 3),
                                    "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
-                                   "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3)},
+                                   "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3),
+                                   "max": round(per_step[-1], 3)},
                 "encoder_tokens_per_s": round(enc_tokens_per_step * args.steps / elapsed, 1),
                 "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
                 "final_nll": round(nll, 5), "roofline": roofline}

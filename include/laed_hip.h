@@ -218,6 +218,7 @@ int laed_scale_by_dev(float* y, const float* x, const float* s, int64_t n, void*
  * layout 0 = NT (x W^T), 1 = NN (dy W), 2 = TN (dy^T x); tile 0 = 128x128, 1 = 64x64.
  * ------------------------------------------------------------------------------------------ */
 int laed_prof_enable(int on);
+int laed_prof_reserve(int n_events);         /* pre-create events (2 per GEMM launch) outside the timed region */
 int laed_prof_collect(double* out_host21);   /* variant 6 = split-bf16 NT 128x128 (see laed_set_gemm_mode) */
 
 /* GEMM math mode (process-wide; default 0, or LAED_GEMM_MODE=bf16x3 in the environment):

@@ -702,6 +702,18 @@ extern "C" int laed_prof_enable(int on) {
     return 0;
 }
 
+// Pre-creates events so that a timed region does not pay hipEventCreate (2 per GEMM launch) inside it.
+extern "C" int laed_prof_reserve(int n_events) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    while ((int)g_prof_pool.size() < n_events) {
+        hipEvent_t e;
+        hipError_t st = hipEventCreate(&e);
+        if (st != hipSuccess) return laed_fail((int)st, "prof_reserve: %s", hipGetErrorString(st));
+        g_prof_pool.push_back(e);
+    }
+    return 0;
+}
+
 // Waits for every recorded launch, then fills out[variant*3 + {0,1,2}] = {launches, total ms, total flops} for the
 // 6 fp32 GEMM variants (NT, NN, TN) x (128x128, 64x64) + variant 6 = split-bf16 NT 128x128, and clears the records.
 // `out` is a HOST array of 21 doubles.

@@ -54,6 +54,7 @@ _SIGS = {
     "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),
     "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),
     "laed_prof_enable": ([_i], _i),
+    "laed_prof_reserve": ([_i], _i),
     "laed_prof_collect": ([ctypes.POINTER(ctypes.c_double)], _i),
     "laed_set_gemm_mode": ([_i], _i),
     "laed_get_gemm_mode": ([], _i),
