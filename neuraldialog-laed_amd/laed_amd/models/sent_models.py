@@ -5,6 +5,7 @@ returned Pack keys as the reference; analysis-only helpers (sweep / enumerate / 
 One deliberate difference, documented in DESIGN.md: valid_loss sums out of place, so loss.nll read after
 backward() is still the clean NLL (the reference aliases and mutates it, sent_models.py:88-90).
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -115,6 +116,61 @@ class DiVAE(_SentBase):
             results['y_ids'] = y_ids
         return results
 
+
+    # ---- GEN-side latent analysis (sent_models.py:167-274): host composition over the same kernels
+    def _decode_codes(self, sample_y, gen_type):
+        """one-hot / mixed latent rows [n, y*k] -> free-running decode from dec_init_connector(sample_y)."""
+        n = sample_y.size(0)
+        dec_init_state = self.dec_init_connector(sample_y)
+        _, _, dec_ctx = self.decoder(n, None, dec_init_state, mode=GEN, gen_type=gen_type, beam_size=self.beam_size)
+        return dec_ctx
+
+    def sweep(self, data_feed, gen_type='greedy'):
+        """Walk from the latent code of the first utterance of the batch to that of the last one, one latent variable
+        at a time, decoding every intermediate code (sent_models.py:167-218).  Returns (dec_ctx, labels, all_y_ids)."""
+        batch_size = len(data_feed['output_lens'])
+        out_utts = self.np2var(data_feed['outputs'], LONG)
+        x_outs, x_last = self.x_encoder(self.embedding(out_utts))
+        x_last = x_last.transpose(0, 1).contiguous().view(-1, self.enc_out_size)
+        qy_logits = self.q_y(x_last).view(-1, self.config.k)
+        sample_y, y_id = self.cat_connector(qy_logits, 1.0, self.use_gpu, hard=True, return_max_id=True)
+        y_id = y_id.view(-1, self.config.y_size)
+        start_y_id, end_y_id = y_id[0], y_id[batch_size - 1]
+        all_y_ids = [start_y_id]
+        for idx in range(self.config.y_size):
+            mask = torch.zeros(self.config.y_size, dtype=torch.long, device=y_id.device)
+            mask[0:idx + 1] = 1
+            all_y_ids.append((1 - mask) * start_y_id + mask * end_y_id)
+        num_steps = len(all_y_ids)
+        all_y_ids = torch.cat(all_y_ids, dim=0).view(num_steps, -1)
+        sample_y = torch.zeros((num_steps * self.config.y_size, self.config.k), device=y_id.device)
+        sample_y.scatter_(1, all_y_ids.view(-1, 1), 1.0)
+        dec_ctx = self._decode_codes(sample_y.view(-1, self.config.k * self.config.y_size), gen_type)
+        return dec_ctx, out_utts[:, 1:].contiguous(), all_y_ids
+
+    def enumerate(self, repeat=1, gen_type='greedy'):
+        """For each latent variable, each of its k values with the other variables at the uniform mixture
+        (sent_models.py:220-248; the row index y*k + k_id*repeat + r is the reference's, kept as is)."""
+        y, k = self.config.y_size, self.config.k
+        sample_y = torch.full((y * k * repeat, y, k), 1.0 / k, device=self.embedding.weight.device)
+        for y_id in range(y):
+            for k_id in range(k):
+                for r_id in range(repeat):
+                    idx = y_id * k + k_id * repeat + r_id
+                    sample_y[idx, y_id] = 0.0
+                    sample_y[idx, y_id, k_id] = 1.0
+        return self._decode_codes(sample_y.view(-1, k * y), gen_type)
+
+    def exp_enumerate(self, repeat=1, gen_type='greedy'):
+        """Every one of the k**y_size joint codes (sent_models.py:250-274).  Returns (dec_ctx, all_y_ids)."""
+        import itertools
+        y, k = self.config.y_size, self.config.k
+        all_y_ids = [list(c) for c in itertools.product(*[range(k)] * y)]
+        n = int(np.power(k, y)) * repeat
+        ids = self.np2var(np.array(all_y_ids), LONG)
+        sample_y = torch.zeros((n * y, k), device=ids.device)
+        sample_y.scatter_(1, ids.view(-1, 1), 1.0)
+        return self._decode_codes(sample_y.view(-1, k * y), gen_type), all_y_ids
 
     def nll_loss_tok(self):
         """Per-token NLL [B,T-1] of the last teacher-forced forward (0 at PAD targets), as a host array."""

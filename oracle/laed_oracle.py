@@ -245,6 +245,47 @@ def divae_greedy(P, cfg, outputs, u, go_id=2, eos_id=3):
     return decoder_greedy(P, 'decoder.', P['embedding.weight'], dec_init, cfg.max_dec_len, go_id, eos_id)
 
 
+def _decode_codes(P, cfg, sample_y, go_id, eos_id):
+    dec_init = F.linear(sample_y, P['dec_init_connector.linear.weight'], None)
+    return decoder_greedy(P, 'decoder.', P['embedding.weight'], dec_init, cfg.max_dec_len, go_id, eos_id)
+
+
+def divae_sweep(P, cfg, outputs, u, go_id=2, eos_id=3):
+    """DiVAE.sweep (sent_models.py:167-218): codes from the first utterance's to the last one's, one variable at a time."""
+    _, _, _, y_ids, _ = _encode_latent(P, cfg, outputs, u, False, 1.0, False)
+    start, end = y_ids[0], y_ids[-1]
+    rows = [start]
+    for idx in range(cfg.y_size):
+        m = torch.zeros(cfg.y_size, dtype=torch.long)
+        m[:idx + 1] = 1
+        rows.append((1 - m) * start + m * end)
+    all_y = torch.stack(rows)
+    sample_y = torch.zeros(all_y.numel(), cfg.k).scatter_(1, all_y.view(-1, 1), 1.0).view(-1, cfg.k * cfg.y_size)
+    return _decode_codes(P, cfg, sample_y, go_id, eos_id), all_y
+
+
+def divae_enumerate(P, cfg, repeat=1, go_id=2, eos_id=3):
+    """DiVAE.enumerate (sent_models.py:220-248), row index y*k + k_id*repeat + r as in the reference."""
+    y, k = cfg.y_size, cfg.k
+    sample_y = torch.full((y * k * repeat, y, k), 1.0 / k)
+    for y_id in range(y):
+        for k_id in range(k):
+            for r_id in range(repeat):
+                idx = y_id * k + k_id * repeat + r_id
+                sample_y[idx, y_id] = 0.0
+                sample_y[idx, y_id, k_id] = 1.0
+    return _decode_codes(P, cfg, sample_y.view(-1, k * y), go_id, eos_id)
+
+
+def divae_exp_enumerate(P, cfg, go_id=2, eos_id=3):
+    """DiVAE.exp_enumerate (sent_models.py:250-274): all k**y joint codes in itertools.product order."""
+    import itertools
+    y, k = cfg.y_size, cfg.k
+    ids = torch.tensor([list(c) for c in itertools.product(*[range(k)] * y)], dtype=torch.long)
+    sample_y = torch.zeros(ids.numel(), k).scatter_(1, ids.view(-1, 1), 1.0).view(-1, k * y)
+    return _decode_codes(P, cfg, sample_y, go_id, eos_id), ids
+
+
 def divst_greedy(P, cfg, outputs, u, go_id=2, eos_id=3):
     _, _, _, _, dec_init = _encode_latent(P, cfg, outputs, u, False, 1.0, True)
     return tuple(decoder_greedy(P, tag + '_decoder.', P['embedding.weight'], dec_init, cfg.max_dec_len,

@@ -77,7 +77,10 @@ def _worker(rank, world, port, result_dir):
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
 
 
-def test_two_rank_step_equals_reference_global_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_step_equals_reference_global_batch(tmp_path, world):
+    """divae_mid has 16 sequences: 8 or 4 per rank.  Loss terms, every gradient and the parameters after one Adam
+    step must equal the reference's single-process global-batch values whatever the rank count."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert sorted(os.listdir(str(tmp_path))) == ["ok0", "ok1"]
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(str(tmp_path))) == ["ok%d" % r for r in range(world)]

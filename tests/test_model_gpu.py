@@ -184,3 +184,23 @@ def test_lazy_logprobs_materialize_matches_reference():
     assert tuple(dec_outs.size()) == G["out/dec_logp"].shape and dec_outs.size(-1) == G["out/dec_logp"].shape[-1]
     dense = dec_outs.view(-1, dec_outs.size(-1)).view(G["out/dec_logp"].shape)
     assert rel_err(dense.cpu(), G["out/dec_logp"]) < 1e-5
+
+
+def test_latent_analysis_entry_points_vs_reference():
+    """DiVAE.sweep / enumerate / exp_enumerate on the HIP decode loop: ids exact vs goldens from the reference."""
+    G = load_golden("divae_gen_tiny")
+    model, cfg = build(G, "divae")
+    model.eval()
+    ud = torch.from_numpy(G["in/u"]).cuda()
+    model.cat_connector.sample_uniform = lambda logits: ud
+    stack = lambda ctx: torch.cat(ctx['sequence'], dim=1).cpu().numpy()
+    with torch.no_grad():
+        ctx, labels, all_y = model.sweep({"outputs": G["in/outputs"], "output_lens": G["in/output_lens"].tolist()})
+        assert np.array_equal(all_y.cpu().numpy(), G["sweep/all_y_ids"])
+        assert np.array_equal(labels.cpu().numpy(), G["sweep/labels"])
+        assert np.array_equal(stack(ctx), G["sweep/sequence"])
+        assert np.array_equal(stack(model.enumerate(repeat=1)), G["enumerate1/sequence"])
+        assert np.array_equal(stack(model.enumerate(repeat=2)), G["enumerate2/sequence"])
+        ctx, ids = model.exp_enumerate()
+        assert np.array_equal(np.array(ids), G["exp_enumerate/all_y_ids"])
+        assert np.array_equal(stack(ctx), G["exp_enumerate/sequence"])

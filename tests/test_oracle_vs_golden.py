@@ -206,3 +206,20 @@ def test_sample_decoding_gumbel_max():
     assert np.array_equal(seq.numpy(), G["sequence"])
     assert list(lengths) == list(G["length"])
     assert rel_err(hT, G["hid"][0]) < 2e-6
+
+
+def test_latent_analysis_entry_points_vs_reference():
+    """DiVAE.sweep / enumerate / exp_enumerate (sent_models.py:167-274): greedy ids and code tables exact."""
+    G = load_golden("divae_gen_tiny")
+    cfg = golden_config(G)
+    P = golden_params(G)
+    (seq, _, _), all_y = O.divae_sweep(P, cfg, G["in/outputs"], G["in/u"])
+    assert np.array_equal(all_y.numpy(), G["sweep/all_y_ids"])
+    assert np.array_equal(seq.numpy(), G["sweep/sequence"])
+    seq, _, _ = O.divae_enumerate(P, cfg, repeat=1)
+    assert np.array_equal(seq.numpy(), G["enumerate1/sequence"])
+    seq, _, _ = O.divae_enumerate(P, cfg, repeat=2)
+    assert np.array_equal(seq.numpy(), G["enumerate2/sequence"])
+    (seq, _, _), ids = O.divae_exp_enumerate(P, cfg)
+    assert np.array_equal(ids.numpy(), G["exp_enumerate/all_y_ids"])
+    assert np.array_equal(seq.numpy(), G["exp_enumerate/sequence"])
