@@ -40,7 +40,7 @@ KERNELS = [
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
-    f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     gru = sum(int(r["Calls"]) for r in rows if re.search(r"gru_step_fwd_kernel|gru_small_fwd_kernel", r["Name"]))
     steps = gru / 79.0

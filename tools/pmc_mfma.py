@@ -18,7 +18,7 @@ def short(name):
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.Counter()
     for r in csv.DictReader(open(f)):

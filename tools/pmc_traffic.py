@@ -38,10 +38,11 @@ def short(name):
 
 def load(d):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-    if len(files) != 1:
-        raise SystemExit("expected one counter_collection.csv under %s, found %d" % (d, len(files)))
+    if not files:
+        raise SystemExit("no counter_collection.csv under %s" % d)
+    newest = max(files, key=os.path.getmtime)        # gpurun merges runs into one tree: take the latest pass
     acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(newest)):
         k = (short(r["Kernel_Name"]), int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
         a = acc[k]
         a[0] += 1

@@ -20,7 +20,7 @@ for name in ("S-fixed", "S-fixed_b512", "P-fixed", "P-varlen", "VST-fixed"):
     json.dump(d, open(os.path.join(DST, "%s_bench_%s_1gpu.json" % (rnd, name)), "w"), indent=1)
     print("%-14s %10.1f tokens/s  %8.3f ms/step" % (name, d["value"], d["ms_per_step"]))
 for name in ("S-fixed", "P-fixed", "VST-fixed"):
-    f = glob.glob(os.path.join(SRC, "prof_" + name, "**", "*kernel_stats.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(SRC, "prof_" + name, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(f, os.path.join(DST, "%s_bench_%s_1gpu_kernel_stats.csv" % (rnd, name)))
     json.dump(json_line(os.path.join(SRC, "prof_%s.json" % name)),
               open(os.path.join(DST, "%s_bench_%s_1gpu_under_rocprof.json" % (rnd, name)), "w"), indent=1)
