@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void gumbel_latent_bwd_kernel(const float* __r
 }
 
 // ---- BPR / MI statistics -------------------------------------------------------------------
-constexpr int STAT_BLOCKS = 128;
+constexpr int STAT_BLOCKS = 256;
 constexpr int MAXE = 8;   // y*k <= 8*256
 
 __global__ __launch_bounds__(256) void latent_stats_kernel(const float* __restrict__ log_qy, int64_t B, int yk, int k,
@@ -103,17 +103,28 @@ __global__ __launch_bounds__(256) void latent_stats_kernel(const float* __restri
     for (int i = 0; i < MAXE; ++i) sq[i] = 0.f;
     float ent = 0.f, kl = 0.f;
     const float logu = logf(1.0f / (float)k);
-    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        const float* row = log_qy + b * yk;
+    // four rows in flight per pass (independent loads), accumulated in row order: the sums do not depend on the unroll
+    constexpr int RU = 4;
+    for (int64_t b0 = blockIdx.x; b0 < B; b0 += (int64_t)gridDim.x * RU) {
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int e = threadIdx.x + i * 256;
             if (e < yk) {
-                const float lq = row[e];
-                const float q = expf(lq);
-                sq[i] += q;
-                ent += -1.0f * lq * q;
-                kl += q * (lq - logu);
+                float lq[RU];
+#pragma unroll
+                for (int r = 0; r < RU; ++r) {
+                    const int64_t b = b0 + (int64_t)r * gridDim.x;
+                    lq[r] = b < B ? log_qy[b * yk + e] : -INFINITY;      // exp(-inf) = 0: contributes nothing
+                }
+#pragma unroll
+                for (int r = 0; r < RU; ++r) {
+                    if (lq[r] != -INFINITY) {
+                        const float q = expf(lq[r]);
+                        sq[i] += q;
+                        ent += -1.0f * lq[r] * q;
+                        kl += q * (lq[r] - logu);
+                    }
+                }
             }
         }
     }
@@ -136,10 +147,13 @@ __global__ __launch_bounds__(256) void latent_stats_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void latent_stats_combine_kernel(const float* __restrict__ ws, int nblk, int n,
                                                                    float* __restrict__ stats) {
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    // one wave per statistic: lanes stride over the block partials, then a fixed shuffle tree (reproducible)
+    const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < n; e += gridDim.x * (blockDim.x >> 6)) {
         float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += ws[(int64_t)b * n + e];   // fixed order: reproducible
-        stats[e] = s;
+        for (int b = lane; b < nblk; b += 64) s += ws[(int64_t)b * n + e];
+        s = wave_sum(s);
+        if (lane == 0) stats[e] = s;
     }
 }
 
@@ -237,7 +251,7 @@ extern "C" int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, f
     const int nblk = (int)(B < STAT_BLOCKS ? B : STAT_BLOCKS);
     hipLaunchKernelGGL(latent_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, B, yk, k, workspace);
     LAED_LAUNCH_CHECK("latent_stats");
-    hipLaunchKernelGGL(latent_stats_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nblk, yk + 2, stats);
+    hipLaunchKernelGGL(latent_stats_combine_kernel, dim3((yk + 2 + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, yk + 2, stats);
     LAED_LAUNCH_CHECK("latent_stats_combine");
     return 0;
 }
