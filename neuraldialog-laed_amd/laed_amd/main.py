@@ -2,8 +2,9 @@
 
 Same step order (zero_grad -> forward(TEACH_FORCE) -> [flush_valid] -> backward -> step), ckpt_step pseudo-epochs,
 patience rule, best-valid checkpoint (`torch.save(model.state_dict())`, reference-compatible keys) and LossManager
-windows/PPL.  Differences: loss scalars are read with .item() (the reference's `val.data[0]` no longer runs on
-0-dim tensors), validation runs under torch.no_grad(), and text generation previews are left to the caller
+windows/PPL.  Differences: loss scalars stay on the device until a print / checkpoint step reads them (the reference's
+per-step `val.data[0]` is a device synchronisation per loss term and no longer runs on 0-dim tensors anyway),
+validation runs under torch.no_grad(), and text generation previews are left to the caller
 (`gen` callback) since tokenisers / BLEU are outside the hot-path scope.
 """
 import logging
@@ -18,28 +19,63 @@ from .enc2dec.decoders import TEACH_FORCE
 logger = logging.getLogger()
 
 
+class _LazyScalars(list):
+    """List of loss scalars that keeps device tensors as they are appended and copies them to the host in ONE transfer
+    when somebody reads the list.  The reference reads every loss term with `val.data[0]` per step (main.py:25), i.e.
+    several device synchronisations per step; here the train loop never waits for the GPU between print steps."""
+
+    def __init__(self):
+        super(_LazyScalars, self).__init__()
+        self._pending = []
+
+    def append(self, val):
+        if torch.is_tensor(val):
+            self._pending.append(val.detach().reshape(1))
+        else:
+            self._flush()
+            super(_LazyScalars, self).append(float(val))
+
+    def _flush(self):
+        if self._pending:
+            vals, self._pending = self._pending, []
+            super(_LazyScalars, self).extend(torch.cat(vals).float().cpu().tolist())
+
+    def __len__(self):
+        self._flush()
+        return super(_LazyScalars, self).__len__()
+
+    def __iter__(self):
+        self._flush()
+        return super(_LazyScalars, self).__iter__()
+
+    def __getitem__(self, i):
+        self._flush()
+        return super(_LazyScalars, self).__getitem__(i)
+
+
 class LossManager(object):
     def __init__(self):
-        self.losses = defaultdict(list)
-        self.backward_losses = []
+        self.losses = defaultdict(_LazyScalars)
+        self.backward_losses = _LazyScalars()
 
     def add_loss(self, loss):
         for key, val in loss.items():
             if val is not None and type(val) is not bool and torch.is_tensor(val) and val.dim() == 0:
-                self.losses[key].append(float(val.detach()))
+                self.losses[key].append(val)
 
     def add_backward_loss(self, loss):
-        self.backward_losses.append(float(loss.detach()))
+        self.backward_losses.append(loss)
 
     def clear(self):
-        self.losses = defaultdict(list)
-        self.backward_losses = []
+        self.losses = defaultdict(_LazyScalars)
+        self.backward_losses = _LazyScalars()
 
     def pprint(self, name, window=None, prefix=None):
         str_losses = []
         for key, loss in self.losses.items():
             if loss is None:
                 continue
+            loss = list(loss)
             avg_loss = np.average(loss) if window is None else np.average(loss[-window:])
             str_losses.append("{} {:.3f}".format(key, avg_loss))
             if 'nll' in key:
@@ -49,7 +85,7 @@ class LossManager(object):
         return "{} {}".format(name, " ".join(str_losses))
 
     def avg_loss(self):
-        return np.mean(self.backward_losses)
+        return np.mean(list(self.backward_losses))
 
 
 def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=None):
