@@ -1,10 +1,13 @@
 """DI-VAE and DI-VST (mirror of laed/models/sent_models.py:20-165, 278-442) on the HIP engine.
 
 Same constructor arguments, config attributes, state_dict keys, forward/valid_loss/backward semantics and
-returned Pack keys as the reference; analysis-only helpers (sweep / enumerate / exp_enumerate) are out of scope.
+returned Pack keys as the reference, including DiVAE's GEN-side latent analysis helpers (sweep / enumerate /
+exp_enumerate).  DiVST runs its two independent decoders on two HIP streams (LAED_VST_STREAMS=0: one stream).
 One deliberate difference, documented in DESIGN.md: valid_loss sums out of place, so loss.nll read after
 backward() is still the clean NLL (the reference aliases and mutates it, sent_models.py:88-90).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -185,6 +188,11 @@ class DiVST(_SentBase):
         self.next_decoder = self._make_decoder()
         self._build_losses(config)
         self.kl_w = 1.0
+        self.two_streams = os.environ.get("LAED_VST_STREAMS", "1") != "0"     # decoders side by side on two HIP streams
+        self._side_stream = None
+        if self.two_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # the next decoder's parameters are accumulated on the default stream and produced on the side stream: intended
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     def backward(self, batch_cnt, loss):
         total_loss = self.valid_loss(loss)
@@ -205,14 +213,36 @@ class DiVST(_SentBase):
 
         prev_labels = prev_utts[:, 1:].contiguous()
         next_labels = next_utts[:, 1:].contiguous()
-        prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
-                                                           gen_type=gen_type, beam_size=self.beam_size)
-        next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state, mode=mode,
-                                                           gen_type=gen_type, beam_size=self.beam_size)
-        if mode == GEN:
-            return (prev_dec_ctx, next_dec_ctx), (prev_labels, next_labels)
-        prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
-        next_nll = self.nll_loss(next_dec_outs, next_labels)
+        if mode != GEN and self.two_streams and dec_init_state.is_cuda:
+            # The two decoders are independent given dec_init_state: the next-utterance branch (decoder + its fused
+            # projection / NLL) runs on a side HIP stream beside the previous-utterance branch.  At the script batch
+            # (60) each recurrence kernel occupies half the chip or less, so the branches overlap almost entirely;
+            # autograd replays every node on its forward stream, so backward overlaps the same way.
+            cur = torch.cuda.current_stream(dec_init_state.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dec_init_state.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for t in (dec_init_state, next_utts, next_labels):
+                    t.record_stream(side)
+                next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state, mode=mode,
+                                                                   gen_type=gen_type, beam_size=self.beam_size)
+                next_nll = self.nll_loss(next_dec_outs, next_labels)
+                next_nll.record_stream(cur)
+            prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
+                                                               gen_type=gen_type, beam_size=self.beam_size)
+            prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
+            cur.wait_stream(side)
+        else:
+            prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
+                                                               gen_type=gen_type, beam_size=self.beam_size)
+            next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state, mode=mode,
+                                                               gen_type=gen_type, beam_size=self.beam_size)
+            if mode == GEN:
+                return (prev_dec_ctx, next_dec_ctx), (prev_labels, next_labels)
+            prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
+            next_nll = self.nll_loss(next_dec_outs, next_labels)
         reg_kl, b_pr, mi = self.bpr_loss(log_qy)
         results = Pack(prev_nll=prev_nll, next_nll=next_nll, reg_kl=reg_kl, mi=mi, b_pr=b_pr)
         if return_latent:

@@ -94,8 +94,9 @@ _WS = {}
 
 
 def workspace(key, numel, device):
-    """Reusable fp32 scratch (grown on demand, one per key/device); contents are undefined between calls."""
-    k = (key, device)
+    """Reusable fp32 scratch (grown on demand, one per key / device / STREAM: two streams of one model -- DiVST's two
+    decoders -- never share scratch); contents are undefined between calls."""
+    k = (key, device, torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(k)
     if t is None or t.numel() < numel:
         t = torch.empty(numel, device=device, dtype=torch.float32)
