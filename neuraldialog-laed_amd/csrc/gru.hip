@@ -23,6 +23,7 @@ struct GruStepArgs {
     float* hout;          // [B][H]
     float* hn;            // [B][H] or NULL
     int B, H;
+    int units_in_x;       // grid = (unit tiles, row tiles) instead of (row tiles, unit tiles)
 };
 
 // WM row tiles x WK K-splits = NT/64 waves (4 waves with K tiles of 32, or 8 waves with K tiles of 64: in both a load
@@ -44,7 +45,10 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wq = wave / WM;
-    const int m0 = blockIdx.x * BR, j0 = blockIdx.y * 32;
+    // blocks are dealt round-robin over the 8 XCDs by their linear id: with the unit tile in blockIdx.x the blocks of one
+    // XCD share 1/8 of the W_hh slices (L2-resident) and differ in their batch rows; with the row tile in blockIdx.x
+    // every XCD streams ALL of W_hh each step (12.6 MB at H = 1024: more than its 4 MB L2)
+    const int m0 = (p.units_in_x ? blockIdx.y : blockIdx.x) * BR, j0 = (p.units_in_x ? blockIdx.x : blockIdx.y) * 32;
     const int B = p.B, H = p.H;
 
     f32x16 acc[3];
@@ -52,6 +56,27 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    // gate-epilogue operands (gi_r, gi_z, gi_n, h_prev of this lane's 16 (row, unit) pairs) are fetched NOW, by the
+    // waves that will apply the gates, and consumed after the K loop: loaded there they were 16 dependent round trips
+    // (the stores of one row alias the loads of the next), ~40 % of the kernel at B = 4096.
+    float pre[16][4];
+    float bhr = 0.f, bhz = 0.f, bhn = 0.f;
+    if (tid / 64 / WM == 0) {                // wq == 0
+        const int jj = j0 + (tid & 31);
+        if (jj < H) {
+            bhr = p.b_hh[jj]; bhz = p.b_hh[H + jj]; bhn = p.b_hh[2 * H + jj];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (tid / 64 % WM) * 32 + (e & 3) + 8 * (e >> 2) + 4 * ((tid & 63) >> 5);
+                if (row < B) {
+                    const float* g = p.gates + (int64_t)row * 3 * H;
+                    pre[e][0] = g[jj]; pre[e][1] = g[H + jj]; pre[e][2] = g[2 * H + jj];
+                    pre[e][3] = p.hprev[(int64_t)row * H + jj];
+                }
+            }
+        }
+    }
 
     float4 rh[NLH], rw[NLW];
     auto load = [&](int k0) {
@@ -167,20 +192,29 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
                     const int q_ = ks * 3 + g;
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1], bf[ks & 1][g], acc[g], 0, 0, 0);
                     if (g == 0 && ks + 1 < KS) {
+#if !defined(GRU_EXP) || !(GRU_EXP & 4)
                         const int o = 2 * (ks + 1) * WK;
                         af[(ks + 1) & 1] = h_s[o * SH];
                         bf[(ks + 1) & 1][0] = w_s[o * SW]; bf[(ks + 1) & 1][1] = w_s[o * SW + 32]; bf[(ks + 1) & 1][2] = w_s[o * SW + 64];
+#else
+                        af[(ks + 1) & 1] = af[ks & 1];
+                        bf[(ks + 1) & 1][0] = bf[ks & 1][0]; bf[(ks + 1) & 1][1] = bf[ks & 1][1]; bf[(ks + 1) & 1][2] = bf[ks & 1][2];
+#endif
                     }
+#if !defined(GRU_EXP) || !(GRU_EXP & 2)
 #pragma unroll
                     for (int u = 0; u < NL; ++u) {
                         const int gs = Q / 8 + (u * (3 * Q / 4)) / NL;      // store gap of unit u
                         if (q_ == gs) store_unit(u, cur ^ 1);               // tile kt+1 -> LDS
                         if (q_ == gs + 1) load_unit(u);                     // tile kt+2 -> registers
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if !defined(GRU_EXP) || !(GRU_EXP & 1)
             __syncthreads();
+#endif
             cur ^= 1;
         }
     }
@@ -228,17 +262,16 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 
     const int j = j0 + lrow;
     if (j >= H) return;
-    const float bhr = p.b_hh[j], bhz = p.b_hh[H + j], bhn = p.b_hh[2 * H + j];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row < B) {
             float* g = p.gates + (int64_t)row * 3 * H;
             const float ghn = acc[2][e] + bhn;
-            const float r = sigmoidf_acc(g[j] + acc[0][e] + bhr);
-            const float z = sigmoidf_acc(g[H + j] + acc[1][e] + bhz);
-            const float n = tanhf(g[2 * H + j] + r * ghn);
-            const float hp = p.hprev[(int64_t)row * H + j];
+            const float r = sigmoidf_acc(pre[e][0] + acc[0][e] + bhr);
+            const float z = sigmoidf_acc(pre[e][1] + acc[1][e] + bhz);
+            const float n = tanhf(pre[e][2] + r * ghn);
+            const float hp = pre[e][3];
             p.hout[(int64_t)row * H + j] = (1.0f - z) * n + z * hp;
             if (p.hn != nullptr) {
                 g[j] = r; g[H + j] = z; g[2 * H + j] = n;
@@ -250,9 +283,14 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 
 template <int WM, int WK, int NT = 256, int BKT = 32>
 int launch_step(const GruStepArgs& a, bool vec, hipStream_t stream) {
-    dim3 grid((a.B + 32 * WM - 1) / (32 * WM), (a.H + 31) / 32);
-    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true, NT, BKT>), grid, dim3(NT), 0, stream, a);
-    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false, NT, BKT>), grid, dim3(NT), 0, stream, a);
+    GruStepArgs b = a;
+    const unsigned mt = (a.B + 32 * WM - 1) / (32 * WM), jt = (a.H + 31) / 32;
+    static const int force_x = []() { const char* e = getenv("LAED_GRU_UNITS_IN_X"); return e ? atoi(e) : -1; }();
+    b.units_in_x = force_x >= 0 ? force_x : 1;
+    if (mt > 65535) b.units_in_x = 1;
+    dim3 grid = b.units_in_x ? dim3(jt, mt) : dim3(mt, jt);
+    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true, NT, BKT>), grid, dim3(NT), 0, stream, b);
+    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false, NT, BKT>), grid, dim3(NT), 0, stream, b);
     LAED_LAUNCH_CHECK("gru_step_fwd");
     return 0;
 }

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblaed_hip.so")
+_SO = os.environ.get("LAED_HIP_LIB") or os.path.join(_HERE, "liblaed_hip.so")    # override: A/B builds of the library
 
 if not os.path.exists(_SO):
     raise ImportError(
