@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     constexpr int NLH = BR * BK / 4 / NT > 0 ? BR * BK / 4 / NT : 1;   // float4 per thread (h tile)
     constexpr int NLW = 96 * BK / 4 / NT;                                // = 3
     constexpr int TILE = BK * (SH + SW);
-    constexpr int RED = (WK > 1) ? (WK - 1) * WM * 64 * 48 : 0;
+    constexpr int RED = (WK > 1) ? WK * WM * 64 * 48 : 0;
     constexpr int SMEM = (2 * TILE > RED) ? 2 * TILE : RED;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* sH = smem;                  // [2][BK][SH]
@@ -57,22 +57,27 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
 
-    // gate-epilogue operands (gi_r, gi_z, gi_n, h_prev of this lane's 16 (row, unit) pairs) are fetched NOW, by the
-    // waves that will apply the gates, and consumed after the K loop: loaded there they were 16 dependent round trips
-    // (the stores of one row alias the loads of the next), ~40 % of the kernel at B = 4096.
-    float pre[16][4];
+    // Gate epilogue: with a 2-way K split the two waves share it -- wave wq applies the gates to rows e in
+    // [wq * EPW, (wq + 1) * EPW) of its 32x32 tiles after the partial sums have met in LDS (B = 4096: -2.7 %); with a
+    // 4-way split (small batches, one block per CU) the wq == 0 wave keeps all 16 rows (sharing measured +10 % there).
+    // Its operands (gi_r, gi_z, gi_n, h_prev of this lane's EPW (row, unit) pairs) are fetched NOW and consumed after the
+    // K loop: loaded there they were dependent round trips (the stores of one row alias the loads of the next).
+    constexpr int EW = (WK == 2) ? 2 : 1;      // waves per row tile that apply gates
+    constexpr int EPW = 16 / EW;
+    float pre[EPW][4];
     float bhr = 0.f, bhz = 0.f, bhn = 0.f;
-    if (tid / 64 / WM == 0) {                // wq == 0
+    if (tid / 64 / WM < EW) {
         const int jj = j0 + (tid & 31);
         if (jj < H) {
             bhr = p.b_hh[jj]; bhz = p.b_hh[H + jj]; bhn = p.b_hh[2 * H + jj];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int ee = 0; ee < EPW; ++ee) {
+                const int e = (tid / 64 / WM) * EPW + ee;
                 const int row = m0 + (tid / 64 % WM) * 32 + (e & 3) + 8 * (e >> 2) + 4 * ((tid & 63) >> 5);
                 if (row < B) {
                     const float* g = p.gates + (int64_t)row * 3 * H;
-                    pre[e][0] = g[jj]; pre[e][1] = g[H + jj]; pre[e][2] = g[2 * H + jj];
-                    pre[e][3] = p.hprev[(int64_t)row * H + jj];
+                    pre[ee][0] = g[jj]; pre[ee][1] = g[H + jj]; pre[ee][2] = g[2 * H + jj];
+                    pre[ee][3] = p.hprev[(int64_t)row * H + jj];
                 }
             }
         }
@@ -237,41 +242,42 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         cur ^= 1;
     }
 
-    if (WK > 1) {   // sum the K-split partial accumulators into the wq == 0 waves
+    if (WK > 1) {   // every wave hands the rows it does not own to their owners (fixed summation order: wq ascending)
         float* red = smem;   // all waves are past the last barrier: tiles are dead
-        if (wq > 0) {
-            float* d = red + (((wq - 1) * WM + wm) * 48) * 64 + lane;
+        float* d = red + ((wq * WM + wm) * 48) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (e / EPW != wq) d[(g * 16 + e) * 64] = acc[g][e];
+        __syncthreads();
+        if (wq >= EW) return;
+#pragma unroll
+        for (int s = 0; s < WK; ++s) {
+            if (s == wq) continue;
+            const float* sp = red + ((s * WM + wm) * 48) * 64 + lane;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d[(g * 16 + e) * 64] = acc[g][e];
-        }
-        __syncthreads();
-        if (wq == 0) {
-#pragma unroll
-            for (int s = 0; s < WK - 1; ++s) {
-                const float* d = red + ((s * WM + wm) * 48) * 64 + lane;
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[g][e] += d[(g * 16 + e) * 64];
-            }
+                for (int e = 0; e < 16; ++e)
+                    if (e / EPW == wq) acc[g][e] += sp[(g * 16 + e) * 64];
         }
     }
-    if (wq != 0) return;
 
     const int j = j0 + lrow;
     if (j >= H) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
+        if (e / EPW != wq) continue;             // compile-time e, wave-uniform wq
         const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (row < B) {
             float* g = p.gates + (int64_t)row * 3 * H;
+            const int ee = e % EPW;
             const float ghn = acc[2][e] + bhn;
-            const float r = sigmoidf_acc(pre[e][0] + acc[0][e] + bhr);
-            const float z = sigmoidf_acc(pre[e][1] + acc[1][e] + bhz);
-            const float n = tanhf(pre[e][2] + r * ghn);
-            const float hp = pre[e][3];
+            const float r = sigmoidf_acc(pre[ee][0] + acc[0][e] + bhr);
+            const float z = sigmoidf_acc(pre[ee][1] + acc[1][e] + bhz);
+            const float n = tanhf(pre[ee][2] + r * ghn);
+            const float hp = pre[ee][3];
             p.hout[(int64_t)row * H + j] = (1.0f - z) * n + z * hp;
             if (p.hn != nullptr) {
                 g[j] = r; g[H + j] = z; g[2 * H + j] = n;
