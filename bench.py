@@ -75,11 +75,14 @@ def make_config(E, H, y, k, T, batch, use_gpu=True):
                      use_mutual=True, use_reg_kl=True, train_prior=False, init_lr=0.001, op='adam', batch_size=batch)
 
 
+IDS = "zipf"      # --ids: interior token distribution (only the embedding-gradient scatter contention depends on it)
+
+
 def synth_batch(V, T, B, seed=1234):
-    """[B,T] int32: <s>=2, Zipf(s=1) interior ids over [4,V), </s>=3 (SURVEY.md 8d 'S-fixed')."""
+    """[B,T] int32: <s>=2, Zipf(s=1) (or uniform) interior ids over [4,V), </s>=3 (SURVEY.md 8d 'S-fixed')."""
     rs = np.random.RandomState(seed)
     ranks = np.arange(1, V - 4 + 1, dtype=np.float64)
-    p = 1.0 / ranks
+    p = 1.0 / ranks if IDS == "zipf" else np.ones_like(ranks)
     p /= p.sum()
     out = np.empty((B, T), dtype=np.int32)
     out[:, 0] = 2
@@ -147,7 +150,10 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32 = exact fp32 MFMA everywhere (default); bf16x3 = opt-in split-bf16 x W^T products")
+    ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform"], help="interior token id distribution")
     args = ap.parse_args()
+    global IDS
+    IDS = args.ids
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,7 +182,7 @@ def main():
     if GB % world:
         raise SystemExit("global batch %d not divisible by %d GPUs" % (GB, world))
     per = GB // world
-    same_job = args.workload == "S-fixed" and GB == SHAPES["S-fixed"][6] and world == 1   # what the PMC passes ran
+    same_job = args.workload == "S-fixed" and GB == SHAPES["S-fixed"][6] and world == 1 and args.ids == "zipf"   # what the PMC passes ran
 
     torch.manual_seed(0)                                     # identical replicas on every rank
     cfg = make_config(E, H, y, k, T, GB)
@@ -308,7 +314,7 @@ def main():
             "encoder_tokens_per_s": main_res["encoder_tokens_per_s"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == "fp32" else "f32 (x W^T products as split-bf16 bf16x3, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": args.workload, "vocab": V, "embed": E, "hidden": H, "y_size": y, "k": k,
+            "config": {"workload": args.workload, "ids": args.ids, "vocab": V, "embed": E, "hidden": H, "y_size": y, "k": k,
                        "seq_len": T, "global_batch": GB, "per_gpu_batch": per, "parallelism": "dp%d" % world,
                        "tokens_per_step": tokens_per_step},
             "step_tflops": main_res["step_tflops"],

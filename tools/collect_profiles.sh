@@ -10,6 +10,7 @@ step() { echo "== $*" >> $O/steps.log; "$@"; rc=$?; echo "rc=$rc" >> $O/steps.lo
 # 1. bench lines (default run = the driver's command; then the other workloads)
 step timeout -k 10 500 python bench.py > $O/bench_S-fixed.json 2> $O/bench_S-fixed.err
 step timeout -k 10 200 python bench.py --global-batch 512 --no-alt --cpu-sample 0 > $O/bench_S-fixed_b512.json 2>> $O/bench.err
+step timeout -k 10 200 python bench.py --ids uniform --no-alt --cpu-sample 0 > $O/bench_S-fixed_uniform.json 2>> $O/bench.err
 for w in P-fixed P-varlen VST-fixed; do
   step timeout -k 10 200 python bench.py --workload $w --steps 50 --warmup 10 --no-alt > $O/bench_$w.json 2>> $O/bench.err
 done
