@@ -65,8 +65,13 @@ int laed_sgemm_ws(int transA, int transB, int M, int N, int K,
  * ------------------------------------------------------------------------------------------ */
 int laed_embed_gather(const int64_t* ids, int64_t rows, const float* table, int V, int E,
                       const uint8_t* keep, float drop_p, float* out, void* stream);
+/* scatter-add with `ws` (laed_embed_scatter_workspace bytes, 256-byte aligned; not needed for rows <= 4096) is
+ * DETERMINISTIC: stable sort of (id, position) + fixed-order segment sums, no float atomics.  ws == NULL for more
+ * than 4096 rows falls back to fp32 atomics (order-dependent rounding). */
+int64_t laed_embed_scatter_workspace(int64_t rows, int V, int E);
 int laed_embed_scatter_add(const int64_t* ids, int64_t rows, const float* dout, int V, int E,
-                           const uint8_t* keep, float drop_p, int64_t pad_id, float* dtable, void* stream);
+                           const uint8_t* keep, float drop_p, int64_t pad_id, float* dtable,
+                           void* ws, int64_t ws_bytes, void* stream);
 int laed_dropout_keep_mask(uint8_t* keep, int64_t n, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 int laed_uniform(float* u, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 

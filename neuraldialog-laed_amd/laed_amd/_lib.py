@@ -27,7 +27,8 @@ _SIGS = {
     "laed_last_error": ([], ctypes.c_char_p),
     "laed_sgemm": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p], _i),
     "laed_embed_gather": ([_p, _i64, _p, _i, _i, _p, _f, _p, _p], _i),
-    "laed_embed_scatter_add": ([_p, _i64, _p, _i, _i, _p, _f, _i64, _p, _p], _i),
+    "laed_embed_scatter_add": ([_p, _i64, _p, _i, _i, _p, _f, _i64, _p, _p, _i64, _p], _i),
+    "laed_embed_scatter_workspace": ([_i64, _i, _i], _i64),
     "laed_dropout_keep_mask": ([_p, _i64, _f, _u64, _u64, _p], _i),
     "laed_uniform": ([_p, _i64, _u64, _u64, _p], _i),
     "laed_gru_fwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i64, _p], _i),

@@ -213,8 +213,11 @@ class EmbedFunction(torch.autograd.Function):
         V, E, p, pad_id = ctx.meta
         dout = _f32c(dout)
         dw = torch.zeros((V, E), device=dout.device, dtype=torch.float32)
+        ws_b = int(lib.laed_embed_scatter_workspace(ids.numel(), V, E))      # deterministic (sorted) scatter-add
+        ws = workspace("scatter", (ws_b + 3) // 4, dout.device) if ws_b > 0 else None
         check(lib.laed_embed_scatter_add(ptr(ids, I64), ids.numel(), ptr(dout), V, E,
-                                         ptr(keep, U8) if keep is not None else None, p, pad_id, ptr(dw), stream()),
+                                         ptr(keep, U8) if keep is not None else None, p, pad_id, ptr(dw),
+                                         ptr(ws), ws_b, stream()),
               "laed_embed_scatter_add")
         return dw, None, None, None, None
 

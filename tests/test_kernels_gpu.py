@@ -320,6 +320,40 @@ def test_embed_gather_scatter(ops):
     assert torch.equal(ops.EmbedFunction.apply(dev(t2), dev(i2), None, 0.0, 0).cpu(), t2[i2])
 
 
+@pytest.mark.parametrize("rows,V,E,use_keep", [(1500, 40, 24, True), (4096, 3000, 8, False), (4097, 97, 20, True),
+                                               (20000, 500, 200, True), (163840, 50000, 16, False), (5000, 3, 7, False)])
+def test_embed_scatter_deterministic(ops, rows, V, E, use_keep):
+    """Dense embedding gradient without float atomics: equals index_add in float64 and is bitwise repeatable, under
+    Zipf-like id repetition, PAD / out-of-range ids and a dropout keep mask; every chunk / run / partial case occurs."""
+    from laed_amd._lib import lib, ptr, check, stream
+    g = torch.Generator().manual_seed(rows + V)
+    w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64)
+    ids = torch.multinomial(w / w.sum(), rows, replacement=True, generator=g)
+    ids[::97] = 0                                   # PAD rows
+    ids[5::301] = V + 3                             # out-of-range ids are skipped too
+    dout = rnd(rows, E, seed=11)
+    keep = (torch.rand(rows, E, generator=g) >= 0.3) if use_keep else None
+    p = 0.3 if use_keep else 0.0
+    ref = torch.zeros(V, E, dtype=torch.float64)
+    ok = (ids != 0) & (ids < V)
+    src = dout.double() * (keep.double() / (1.0 - p) if use_keep else 1.0)
+    ref.index_add_(0, ids[ok], src[ok])
+    outs = []
+    for _ in range(2):
+        dw = dev(torch.ones(V, E))                  # accumulates into existing contents
+        ws_b = int(lib.laed_embed_scatter_workspace(rows, V, E))
+        assert (ws_b == 0) == (rows <= 4096)
+        ws = torch.empty((ws_b + 3) // 4, device="cuda") if ws_b else None
+        kd = dev(keep.to(torch.uint8)) if use_keep else None
+        idd, dd = dev(ids), dev(dout)               # keep the device tensors alive across the launch
+        check(lib.laed_embed_scatter_add(ptr(idd, torch.int64), rows, ptr(dd), V, E,
+                                         ptr(kd, torch.uint8) if use_keep else None, p, 0, ptr(dw), ptr(ws), ws_b, stream()), "scatter")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0].double() - 1.0, ref) < 2e-6
+    assert float((outs[0][0] - 1.0).abs().max()) == 0.0
+
+
 def test_rng_fills(ops):
     u = ops.uniform(100000, 1234, 0, "cuda").cpu()
     assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
