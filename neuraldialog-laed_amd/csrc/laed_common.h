@@ -29,6 +29,10 @@ static inline int laed_fail(int code, const char* fmt, ...) {
 
 #define LAED_TRY(expr) do { int s_ = (expr); if (s_ != 0) return s_; } while (0)
 
+#define LAED_HIP_TRY(expr) \
+    do { hipError_t e_ = (expr); \
+         if (e_ != hipSuccess) return laed_fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -383,7 +383,13 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
                              float* tok_nll, float* lse, float* dh, float* dW, float* db, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAED_CHECK_ARG(N >= 0 && H > 0 && V > 0 && chunk_rows > 0, "proj_nll: bad size");
-    if (N == 0) return 0;
+    if (N == 0) {      // an empty row set contributes nothing: dW / db are still outputs and must not stay undefined
+        if (with_grad && !accumulate_w) {
+            if (dW) LAED_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)V * H, stream));
+            if (db) LAED_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * (size_t)V, stream));
+        }
+        return 0;
+    }
     LAED_CHECK_ARG(h && W && labels && workspace && tok_nll, "proj_nll: null pointer");
     LAED_CHECK_ARG(!with_grad || (dh && dW && db), "proj_nll: with_grad needs dh, dW, db");
     LAED_CHECK_ARG(aligned16(workspace), "proj_nll: workspace must be 16-byte aligned");

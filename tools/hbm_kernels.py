@@ -29,7 +29,9 @@ KERNELS = [
      "GRU gate gradients: 7 floats read + 7 written per (b, t, unit)"),
     (r"adam_kernel", PARAMS * 28, "Adam: read p, g, m, v; write p, m, v"),
     (r"embed_gather_kernel", (B * T + B * (T - 1)) * E * 4 * 2, "embedding rows gathered and written (enc + dec inputs)"),
-    (r"embed_scatter_kernel", (B * T + B * (T - 1)) * E * 4 * 2, "embedding gradient rows read + atomically added"),
+    (r"embed_scatter_kernel|embed_scatter_small_kernel|sc_keys_kernel|sc_chunks_kernel|sc_partials_kernel|rocprim.*radix|rocprim.*onesweep|rocprim.*sort",
+     (B * T + B * (T - 1)) * E * 4 * 2,
+     "embedding gradient rows read + added into the table (sorted scatter-add: keys, radix sort, chunk sums, per-id pass)"),
     (r"gumbel_latent_fwd_kernel", B * Y * K * 4 * 4 + B * Y * 8, "logits, u in; y, log_qy, ids out"),
     (r"gumbel_latent_bwd_kernel", B * Y * K * 4 * 5, "y, log_qy, dy, dlog_qy in; dlogits out"),
     (r"latent_stats_kernel", B * Y * K * 4, "log_qy read once (batch-mean posterior, entropies)"),
