@@ -4,8 +4,8 @@ Same step order (zero_grad -> forward(TEACH_FORCE) -> [flush_valid] -> backward 
 patience rule, best-valid checkpoint (`torch.save(model.state_dict())`, reference-compatible keys) and LossManager
 windows/PPL.  Differences: loss scalars stay on the device until a print / checkpoint step reads them (the reference's
 per-step `val.data[0]` is a device synchronisation per loss term and no longer runs on 0-dim tensors anyway),
-validation runs under torch.no_grad(), and text generation previews are left to the caller
-(`gen` callback) since tokenisers / BLEU are outside the hot-path scope.
+validation runs under torch.no_grad().  `get_sent` / `generate` (laed/main.py:52-78,184-243) turn greedy / sampled id
+matrices back into text for the `gen` callback and the BLEU evaluator.
 """
 import logging
 import os
@@ -14,7 +14,9 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from .enc2dec.decoders import TEACH_FORCE
+from .dataset.corpora import EOS, EOT, PAD
+from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
+from .utils import get_dekenize
 
 logger = logging.getLogger()
 
@@ -164,3 +166,82 @@ def validate(model, valid_feed, config, batch_cnt=None):
     logger.info(losses.pprint(valid_feed.name))
     logger.info("Total valid loss {}".format(valid_loss))
     return valid_loss
+
+
+def get_sent(model, de_tknize, data, b_id, attn=None, attn_ctx=None, stop_eos=True, stop_pad=True):
+    """Row b_id of an id matrix as text (laed/main.py:52-78): stops at </s> / </t> (keeping </t>) and at PAD; with
+    attention scores, also lists the context words that got more than 0.1 of the mass."""
+    words, attn_words = [], []
+    has_attn = attn is not None and attn_ctx is not None
+    for t_id in range(data.shape[1]):
+        w = model.vocab[int(data[b_id, t_id])]
+        if has_attn:
+            a_val = np.max(attn[b_id, t_id])
+            if a_val > 0.1:
+                attn_words.append("{}({})".format(model.vocab[int(attn_ctx[b_id, np.argmax(attn[b_id, t_id])])], a_val))
+        if (stop_eos and w in (EOS, EOT)) or (stop_pad and w == PAD):
+            if w == EOT:
+                words.append(w)
+            break
+        if w != PAD:
+            words.append(w)
+    att = "Attention: {}".format(" ".join(attn_words)) if attn_words else ""
+    try:
+        return de_tknize(words), att if has_attn else ""
+    except Exception:                       # a detokeniser that rejects the tokens: plain join, as the reference
+        return " ".join(words), ""
+
+
+def sequences_of(ret_dict):
+    """[B, max_len] int matrix of generated ids from a decoder's ret_dict (list of [B,1] id tensors per step)."""
+    seq = ret_dict[DecoderRNN.KEY_SEQUENCE]
+    if len(seq) == 0:
+        return np.zeros((0, 0), dtype=int)
+    return torch.cat([t.reshape(-1, 1) for t in seq], dim=1).cpu().numpy().astype(int)      # one device->host copy
+
+
+def generate(model, data_feed, config, evaluator, num_batch=1, dest_f=None):
+    """Response generation over a dialog feed with per-domain BLEU (laed/main.py:184-243)."""
+    model.eval()
+    de_tknize = get_dekenize()
+
+    def write(msg):
+        if msg is None or msg == '':
+            return
+        if dest_f is None:
+            logger.info(msg)
+        else:
+            dest_f.write(msg + '\n')
+
+    data_feed.epoch_init(config, shuffle=num_batch is not None, verbose=False)
+    evaluator.initialize()
+    logger.info("Generation: {} batches".format(data_feed.num_batch if num_batch is None else num_batch))
+    while True:
+        batch = data_feed.next_batch()
+        if batch is None or (num_batch is not None and data_feed.ptr > num_batch):
+            break
+        with torch.no_grad():
+            outputs, labels = model(batch, mode=GEN, gen_type=config.gen_type)
+        pred_labels = sequences_of(outputs)
+        true_labels = labels.cpu().numpy()
+        pred_attns = None
+        if (getattr(config, 'use_attn', False) or getattr(config, 'use_ptr', False)) and DecoderRNN.KEY_ATTN_SCORE in outputs:
+            pred_attns = np.array([t.cpu().numpy() for t in outputs[DecoderRNN.KEY_ATTN_SCORE]], dtype=float).squeeze(2).swapaxes(0, 1)
+        ctx, ctx_len = batch.get('contexts'), batch.get('context_lens')
+        domains = batch.get('domains')
+        for b_id in range(pred_labels.shape[0]):
+            pred_str, attn = get_sent(model, de_tknize, pred_labels, b_id, attn=pred_attns)
+            true_str, _ = get_sent(model, de_tknize, true_labels, b_id)
+            prev_ctx = ""
+            if ctx is not None:
+                ctx_str, _ = get_sent(model, de_tknize, ctx[:, ctx_len[b_id] - 1, :], b_id)
+                prev_ctx = "Source: {}".format(ctx_str)
+            domain = domains[b_id] if domains is not None else 'default'
+            evaluator.add_example(true_str, pred_str, domain)
+            if num_batch is None or num_batch <= 2:
+                write(prev_ctx)
+                write("{}:: True: {} ||| Pred: {}".format(domain, true_str, pred_str))
+                if attn:
+                    write("[[{}]]".format(attn))
+    write(evaluator.get_report(include_error=dest_f is not None))
+    logger.info("Generation Done")

@@ -1,7 +1,13 @@
 """Host plumbing shared with the reference's `laed.utils` (Pack, cast_type, dtype tags, str2bool).
 
-Reference: laed/utils.py:17-55,119-142.  Tokenisers / session-dir helpers are out of scope.
+Reference: laed/utils.py:17-55,119-157.  The tokenisers are the reference's regular expressions (`nltk.RegexpTokenizer`
+= `re.findall` with UNICODE | MULTILINE | DOTALL); the detokeniser stands in for nltk's MosesDetokenizer (absent here:
+PARITY UNPINNED), with the English punctuation / contraction rules that matter for the corpora's lower-cased text.
+Session-dir helpers are out of scope.
 """
+import re
+from collections import defaultdict
+
 import torch
 
 INT = 0
@@ -42,3 +48,35 @@ def cast_type(var, dtype, use_gpu):
         raise ValueError("Unknown dtype")
     var = var.to(_DTYPES[dtype])
     return var.cuda(non_blocking=True) if use_gpu else var.cpu()
+
+
+_RE_FLAGS = re.UNICODE | re.MULTILINE | re.DOTALL
+_TOKEN = re.compile(r'\w+|#\w+|<\w+>|%\w+|[^\w\s]+', _RE_FLAGS)          # laed/utils.py:150
+_CHAT_TOKEN = re.compile(r'\w+|<sil>|[^\w\s]+', _RE_FLAGS)                # laed/utils.py:154
+_NO_SPACE_BEFORE = re.compile(r" ([.,!?;:%)\]}]|'s|'m|'d|'re|'ve|'ll|n't)(?= |$)")
+_NO_SPACE_AFTER = re.compile(r"(^| )([(\[{$#]) ")
+
+
+def get_tokenize():
+    return _TOKEN.findall
+
+
+def get_chat_tokenize():
+    return _CHAT_TOKEN.findall
+
+
+def get_dekenize():
+    """tokens -> sentence: joined by blanks, closing punctuation and English clitics attached to the word before
+    them, opening brackets / currency signs to the word after."""
+    def detokenize(tokens):
+        s = " ".join(tokens)
+        s = _NO_SPACE_BEFORE.sub(r"\1", s)
+        return _NO_SPACE_AFTER.sub(r"\1\2", s)
+    return detokenize
+
+
+class missingdict(defaultdict):
+    """defaultdict whose missing keys are not stored (laed/utils.py:157-159)."""
+
+    def __missing__(self, key):
+        return self.default_factory()

@@ -142,3 +142,31 @@ def test_dialog_models_state_dict_and_freeze_switch():
         assert [int(p.requires_grad) for _, p in model.named_parameters()] == [int(r) for r in G["flip/requires_grad"]]
         assert float(model.model_sel_loss(loss, cfg.freeze_step + 1)) == 0.75
         assert float(loss.nll) == 2.0          # valid_loss is out of place here (the reference mutates loss.nll)
+
+
+def test_corpus_bleu_known_answers_and_tokenizers():
+    """corpus_bleu restates nltk's (absent here): the worked examples nltk's own docstrings quote for the BLEU paper's
+    sentences (sentence_bleu 0.5045..., corpus_bleu 0.5920...), smoothing 1 on an empty 4-gram match, and the edge
+    rules (no unigram match -> 0, brevity penalty from the closest reference length)."""
+    import math
+    from laed_amd.evaluators import corpus_bleu
+    from laed_amd.utils import get_chat_tokenize, get_dekenize, get_tokenize
+    hyp1 = "It is a guide to action which ensures that the military always obeys the commands of the party".split()
+    ref1a = "It is a guide to action that ensures that the military will forever heed Party commands".split()
+    ref1b = ("It is the guiding principle which guarantees the military forces always being under the command of the "
+             "Party").split()
+    ref1c = "It is the practical guide for the army always to heed the directions of the party".split()
+    hyp2 = "he read the book because he was interested in world history".split()
+    ref2a = "he was interested in world history because he read the book".split()
+    assert abs(corpus_bleu([[ref1a, ref1b, ref1c]], [hyp1]) - 0.5045666840058485) < 1e-12
+    assert abs(corpus_bleu([[ref1a, ref1b, ref1c], [ref2a]], [hyp1, hyp2]) - 0.5920778868801042) < 1e-12
+    assert corpus_bleu([[ref2a]], [ref2a]) == 1.0
+    assert corpus_bleu([[["a", "b"]]], [["c", "d"]]) == 0.0
+    # 1-gram 3/4, 2-gram 1/3, 3- and 4-gram numerators 0 -> 0.1/2 and 0.1/1; hyp (4) shorter than ref (5): bp = e^(1-5/4)
+    got = corpus_bleu([[["a", "b", "c", "d", "e"]]], [["a", "b", "d", "x"]])
+    want = math.exp(1 - 5.0 / 4) * math.exp(0.25 * (math.log(3 / 4) + math.log(1 / 3) + math.log(0.1 / 2) + math.log(0.1 / 1)))
+    assert abs(got - want) < 1e-12
+    assert corpus_bleu([[["a", "b", "c", "d", "e"]]], [["a", "b", "d", "x"]], smooth=False) == 0.0
+    assert get_tokenize()("hello <s> #tag %x, isn't it?") == ['hello', '<s>', '#tag', '%x', ',', 'isn', "'", 't', 'it', '?']
+    assert get_chat_tokenize()("ok <sil> fine!") == ['ok', '<sil>', 'fine', '!']
+    assert get_dekenize()(['i', 'do', "n't", 'know', ',', 'it', "'s", '(', 'ok', ')', '.']) == "i don't know, it's (ok)."
