@@ -136,6 +136,23 @@ int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale,
                     int64_t B, double B_global, int y, int k, float* dlog_qy, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CatKLLoss / Entropy on arbitrary rows (the general criterions, outside the fused block above).
+ * Replaces criterions.py:97-109 (CatKLLoss.forward: sum_k exp(lq) (lq - lp) per row, then mean over rows or
+ * sum / batch_size) and criterions.py:136-147 (Entropy.forward: sum_k -lq exp(lq); pass log_py = NULL).
+ *  log_qy [R][k], k <= 64.  log_py is [py_rows][py_cols] with py_rows in {1, R} and py_cols in {1, k} (the
+ *  broadcasts torch allows: the 1-element log_uniform_y of sent_models.py:81, a [k] prior, a full [R,k] prior).
+ *  fwd: out[0] = scale * sum_r row_r  (scale = 1/R for unit_average, 1/batch_size otherwise); rows_out[R]
+ *       optional; partials: laed_cat_rows_blocks() floats of scratch; fixed-order reduction (reproducible).
+ *  bwd: dlog_qy = gscale[0]*scale * q (lq - lp + 1)   (entropy: -q (lq + 1));  dlog_py = -gscale[0]*scale * q,
+ *       only for a full-shape log_py.  gscale == NULL means 1.
+ * ------------------------------------------------------------------------------------------ */
+int laed_cat_rows_blocks(void);
+int laed_cat_rows_fwd(const float* log_qy, const float* log_py, int64_t py_rows, int py_cols, int64_t R, int k,
+                      float scale, float* rows_out, float* partials, float* out, void* stream);
+int laed_cat_rows_bwd(const float* log_qy, const float* log_py, int64_t py_rows, int py_cols, int64_t R, int k,
+                      const float* gscale, float scale, float* dlog_qy, float* dlog_py, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Vocabulary projection fused with log-softmax + NLL (+ its backward), logits never materialised
  * beyond a [chunk_rows][ldl] workspace.
  * Replaces decoders.py:165-166 (project + log_softmax) and criterions.py:43-72 (F.nll_loss,
@@ -203,6 +220,15 @@ int laed_gru_decode_sample(const float* emb, const float* w_ih, const float* w_h
 /* masked reductions used by NLLEntropy's averaging modes (criterions.py:47-68):
  * out[0] = sum_r tok_nll[r], out[1] = #(labels != pad). */
 int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int64_t N, int64_t pad_id, float* out, void* stream);
+
+/* NLLEntropy on a dense log-prob tensor (criterions.py:43-72 handed a materialised [N,V] input instead of the lazy
+ * decoder handle): tok_nll[r] = labels[r] == pad_id ? 0 : -logp[r][labels[r]]  (row stride ld >= V);
+ * bwd: dlogp = 0 except dlogp[r][labels[r]] = -gscale[0]*row_scale[r] on non-pad rows.  A label outside [0,V)
+ * that is not pad_id gives NaN (F.nll_loss raises there). */
+int laed_nll_gather_fwd(const float* logp, int64_t ld, const int64_t* labels, int64_t N, int V, int64_t pad_id,
+                        float* tok_nll, void* stream);
+int laed_nll_gather_bwd(const int64_t* labels, const float* row_scale, const float* gscale, int64_t N, int V,
+                        int64_t pad_id, float* dlogp, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam defaults; model_bases.py:122-125): in place on p, m, v.  `step` is 1-based.

@@ -206,6 +206,72 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
     }
 }
 
+// ---- generic CatKLLoss / Entropy rows (criterions.py:93-109, 132-147) ------------------------
+// row value  KL: sum_c q (lq - lp)   /  entropy (lp == nullptr): sum_c -1 * lq * q,   q = exp(lq)
+// log_py is addressed as lp[(row % py_rows) * py_cols + (c % py_cols)] with py_rows in {1, R}, py_cols in {1, k}:
+// the broadcasts torch allows between a [R,k] log_qy and a 1-element / [k] / [1,k] / [R,1] / [R,k] log_py.
+constexpr int CATROW_BLOCKS = 256;
+
+template <int W>
+__global__ __launch_bounds__(256) void cat_rows_fwd_kernel(const float* __restrict__ log_qy, const float* __restrict__ log_py,
+                                                           int64_t py_rows, int py_cols, int64_t R, int k,
+                                                           float* __restrict__ rows_out, float* __restrict__ part) {
+    constexpr int RPB = 256 / W;
+    __shared__ float red[4];
+    const int c = threadIdx.x % W, g = threadIdx.x / W;
+    float acc = 0.f;      // lane 0 of each sub-group: this sub-group's rows, in row order
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < R; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t row = r0 + g;
+        const bool valid = (row < R) && (c < k);
+        float v = 0.f;
+        if (valid) {
+            const float lq = log_qy[row * k + c];
+            const float q = expf(lq);
+            if (log_py != nullptr) v = q * (lq - log_py[(row % py_rows) * py_cols + (c % py_cols)]);
+            else v = -1.0f * lq * q;
+        }
+        v = grp_sum<W>(v);
+        if (valid && c == 0) {
+            if (rows_out != nullptr) rows_out[row] = v;
+            acc += v;
+        }
+    }
+    acc = wave_sum(acc);                                 // fixed tree over the wave's sub-groups
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void cat_rows_combine_kernel(const float* __restrict__ part, int nblk, float scale,
+                                                              float* __restrict__ out) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[b];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+__global__ __launch_bounds__(256) void cat_rows_bwd_kernel(const float* __restrict__ log_qy, const float* __restrict__ log_py,
+                                                           int64_t py_rows, int py_cols, int64_t R, int k,
+                                                           const float* __restrict__ gscale, float scale,
+                                                           float* __restrict__ dlog_qy, float* __restrict__ dlog_py) {
+    const float g = (gscale ? gscale[0] : 1.0f) * scale;
+    const int64_t n = R * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float lq = log_qy[i];
+        const float q = expf(lq);
+        if (log_py != nullptr) {
+            const int64_t row = i / k;
+            const int c = (int)(i - row * k);
+            const float lp = log_py[(row % py_rows) * py_cols + (c % py_cols)];
+            if (dlog_qy != nullptr) dlog_qy[i] = g * q * ((lq - lp) + 1.0f);     // d/dlq  q (lq - lp)
+            if (dlog_py != nullptr) dlog_py[i] = -g * q;                          // full-shape log_py only
+        } else if (dlog_qy != nullptr) {
+            dlog_qy[i] = -g * q * (lq + 1.0f);                                    // d/dlq  -lq q
+        }
+    }
+}
+
 }   // namespace
 
 #define DISPATCH_W(k, CALL)                         \
@@ -273,5 +339,45 @@ extern "C" int laed_latent_bwd(const float* log_qy, const float* coef, const flo
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, coef, gscale, use_mutual, n,
                        y * k, k, (float)(B_global * y), dlog_qy, accumulate);
     LAED_LAUNCH_CHECK("latent_bwd");
+    return 0;
+}
+
+extern "C" int laed_cat_rows_blocks(void) { return CATROW_BLOCKS; }
+
+static bool cat_rows_py_ok(const float* log_py, int64_t py_rows, int py_cols, int64_t R, int k) {
+    return log_py == nullptr || ((py_rows == 1 || py_rows == R) && (py_cols == 1 || py_cols == k));
+}
+
+extern "C" int laed_cat_rows_fwd(const float* log_qy, const float* log_py, int64_t py_rows, int py_cols, int64_t R, int k,
+                                 float scale, float* rows_out, float* partials, float* out, void* stream) {
+    LAED_CHECK_ARG(R > 0 && k > 0 && k <= 64, "cat_rows_fwd: need R > 0 and 0 < k <= 64 (got R=%lld k=%d)", (long long)R, k);
+    LAED_CHECK_ARG(log_qy && partials && out, "cat_rows_fwd: null pointer");
+    LAED_CHECK_ARG(cat_rows_py_ok(log_py, py_rows, py_cols, R, k), "cat_rows_fwd: log_py [%lld,%d] does not broadcast to [%lld,%d]",
+                   (long long)py_rows, py_cols, (long long)R, k);
+    int nblk = 0;
+#define CALL(W) do { nblk = (int)(cdiv64(R, 256 / W) < CATROW_BLOCKS ? cdiv64(R, 256 / W) : CATROW_BLOCKS); \
+                     hipLaunchKernelGGL((cat_rows_fwd_kernel<W>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, log_py, \
+                                        py_rows, py_cols, R, k, rows_out, partials); } while (0)
+    DISPATCH_W(k, CALL);
+#undef CALL
+    LAED_LAUNCH_CHECK("cat_rows_fwd");
+    hipLaunchKernelGGL(cat_rows_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblk, scale, out);
+    LAED_LAUNCH_CHECK("cat_rows_combine");
+    return 0;
+}
+
+extern "C" int laed_cat_rows_bwd(const float* log_qy, const float* log_py, int64_t py_rows, int py_cols, int64_t R, int k,
+                                 const float* gscale, float scale, float* dlog_qy, float* dlog_py, void* stream) {
+    LAED_CHECK_ARG(R > 0 && k > 0 && k <= 64, "cat_rows_bwd: need R > 0 and 0 < k <= 64 (got R=%lld k=%d)", (long long)R, k);
+    LAED_CHECK_ARG(log_qy && (dlog_qy || dlog_py), "cat_rows_bwd: null pointer");
+    LAED_CHECK_ARG(cat_rows_py_ok(log_py, py_rows, py_cols, R, k), "cat_rows_bwd: log_py [%lld,%d] does not broadcast to [%lld,%d]",
+                   (long long)py_rows, py_cols, (long long)R, k);
+    LAED_CHECK_ARG(dlog_py == nullptr || (log_py && py_rows == R && py_cols == k),
+                   "cat_rows_bwd: a gradient for log_py needs a full-shape [R,k] log_py");
+    const int64_t n = R * k;
+    const int nblk = (int)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
+    hipLaunchKernelGGL(cat_rows_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, log_py, py_rows, py_cols, R, k,
+                       gscale, scale, dlog_qy, dlog_py);
+    LAED_LAUNCH_CHECK("cat_rows_bwd");
     return 0;
 }

@@ -283,6 +283,28 @@ __global__ __launch_bounds__(1024) void dot_kernel(const float* __restrict__ a, 
     }
 }
 
+// Dense log-prob input (NLLEntropy handed a materialised [N,V] tensor, criterions.py:43-72): label gather and its
+// scatter gradient.  A label outside [0,V) that is not the ignore index poisons its row with NaN (F.nll_loss raises).
+__global__ __launch_bounds__(256) void nll_gather_fwd_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ labels,
+                                                             int64_t N, int V, int64_t pad_id, float* __restrict__ tok) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lab = labels[r];
+        float v = 0.f;
+        if (lab != pad_id) v = (lab >= 0 && lab < V) ? -logp[r * ld + lab] : NAN;
+        tok[r] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nll_gather_bwd_kernel(const int64_t* __restrict__ labels, const float* __restrict__ row_scale,
+                                                             const float* __restrict__ gscale, int64_t N, int V, int64_t pad_id,
+                                                             float* __restrict__ dlogp, int64_t ld) {
+    const float g = gscale ? gscale[0] : 1.0f;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lab = labels[r];
+        if (lab != pad_id && lab >= 0 && lab < V) dlogp[r * ld + lab] = -g * row_scale[r];
+    }
+}
+
 // dst[c][r] = src[r][c] for a [R][C] fp32 matrix (row stride ld), dst row stride ldd.  64x64 tiles through a
 // padded LDS tile, float4 (16-byte) accesses on both sides when alignment allows: HBM-bound.
 template <bool VEC>
@@ -465,5 +487,29 @@ extern "C" int laed_dot(const float* a, const float* b, int64_t n, float* out, v
     LAED_CHECK_ARG(a && b && out, "dot: null pointer");
     hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, out);
     LAED_LAUNCH_CHECK("dot");
+    return 0;
+}
+
+extern "C" int laed_nll_gather_fwd(const float* logp, int64_t ld, const int64_t* labels, int64_t N, int V, int64_t pad_id,
+                                   float* tok_nll, void* stream) {
+    LAED_CHECK_ARG(N >= 0 && V > 0 && ld >= V, "nll_gather_fwd: need V > 0 and ld >= V (got V=%d ld=%lld)", V, (long long)ld);
+    if (N == 0) return 0;
+    LAED_CHECK_ARG(logp && labels && tok_nll, "nll_gather_fwd: null pointer");
+    const int nblk = (int)(cdiv64(N, 256) < 1024 ? cdiv64(N, 256) : 1024);
+    hipLaunchKernelGGL(nll_gather_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, logp, ld, labels, N, V, pad_id, tok_nll);
+    LAED_LAUNCH_CHECK("nll_gather_fwd");
+    return 0;
+}
+
+extern "C" int laed_nll_gather_bwd(const int64_t* labels, const float* row_scale, const float* gscale, int64_t N, int V,
+                                   int64_t pad_id, float* dlogp, int64_t ld, void* stream) {
+    LAED_CHECK_ARG(N >= 0 && V > 0 && ld >= V, "nll_gather_bwd: need V > 0 and ld >= V (got V=%d ld=%lld)", V, (long long)ld);
+    if (N == 0) return 0;
+    LAED_CHECK_ARG(labels && row_scale && dlogp, "nll_gather_bwd: null pointer");
+    LAED_HIP_TRY(hipMemsetAsync(dlogp, 0, (size_t)N * (size_t)ld * sizeof(float), (hipStream_t)stream));
+    const int nblk = (int)(cdiv64(N, 256) < 1024 ? cdiv64(N, 256) : 1024);
+    hipLaunchKernelGGL(nll_gather_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, labels, row_scale, gscale, N, V, pad_id,
+                       dlogp, ld);
+    LAED_LAUNCH_CHECK("nll_gather_bwd");
     return 0;
 }

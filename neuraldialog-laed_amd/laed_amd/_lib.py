@@ -42,6 +42,9 @@ _SIGS = {
     "laed_latent_stats": ([_p, _i64, _i, _i, _p, _p, _p], _i),
     "laed_latent_finalize": ([_p, _d, _i, _i, _p, _p, _p], _i),
     "laed_latent_bwd": ([_p, _p, _p, _i, _i64, _d, _i, _i, _p, _i, _p], _i),
+    "laed_cat_rows_blocks": ([], _i),
+    "laed_cat_rows_fwd": ([_p, _p, _i64, _i, _i64, _i, _f, _p, _p, _p, _p], _i),
+    "laed_cat_rows_bwd": ([_p, _p, _i64, _i, _i64, _i, _p, _f, _p, _p, _p], _i),
     "laed_proj_nll_ldl": ([_i], _i),
     "laed_proj_nll_workspace": ([_i, _i, _i], _i64),
     "laed_proj_nll": ([_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _i, _p, _i64, _i, _p, _p, _p, _p, _p, _p], _i),
@@ -51,6 +54,8 @@ _SIGS = {
     "laed_log_softmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_argmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_nll_reduce": ([_p, _p, _i64, _i64, _p, _p], _i),
+    "laed_nll_gather_fwd": ([_p, _i64, _p, _i64, _i, _i64, _p, _p], _i),
+    "laed_nll_gather_bwd": ([_p, _p, _p, _i64, _i, _i64, _p, _i64, _p], _i),
     "laed_adam_step": ([_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _f, _p], _i),
     "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),
     "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),

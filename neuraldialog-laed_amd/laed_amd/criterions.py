@@ -13,7 +13,7 @@ class NLLEntropy(_Loss):
 
     `net_output` is normally the lazy log-prob handle returned by DecoderRNN (teacher forcing): the vocabulary
     projection, log-softmax, NLL and their backward then run fused, and the [B,T,V] tensor is never formed.
-    A dense log-prob tensor is also accepted (label gather only; averaging on the same kernels).
+    A dense log-prob tensor is also accepted (`laed_nll_gather_fwd/bwd`: label gather and its scatter gradient).
     Under data parallelism 'word' divides by the GLOBAL non-PAD count and 'seq'/'real_word' by the global batch.
     """
 
@@ -45,38 +45,51 @@ class NLLEntropy(_Loss):
     def forward(self, net_output, labels):
         from .enc2dec.decoders import LazyLogProbs
         B, T = labels.shape[0], labels.shape[1]
-        scale_tm = self._row_scale(labels, B, T).t().contiguous().view(-1)
-        labels_tm = labels.t().contiguous().view(-1)
         if isinstance(net_output, LazyLogProbs):
+            scale_tm = self._row_scale(labels, B, T).t().contiguous().view(-1)
+            labels_tm = labels.t().contiguous().view(-1)
             loss, tok = ops.ProjNLLFunction.apply(net_output.h_tm.reshape(B * T, -1), net_output.project.weight,
                                                   net_output.project.bias, labels_tm, scale_tm, self.padding_idx)
             net_output.tok_nll = tok.view(T, B).t()
             return loss
-        logp = net_output.reshape(B * T, -1)
-        tok = -logp.gather(1, labels.reshape(-1, 1)).squeeze(1) * (labels.reshape(-1) != self.padding_idx).float()
-        return torch.sum(tok * scale_tm.view(T, B).t().reshape(-1))
+        # a materialised [B,T,V] log-prob tensor: label gather + weighted sum on the HIP kernels (batch-first rows)
+        scale_bf = self._row_scale(labels, B, T).contiguous().view(-1)
+        loss, _tok = ops.NLLGatherFunction.apply(net_output.reshape(B * T, -1), labels.reshape(-1).contiguous(), scale_bf,
+                                                 self.padding_idx)
+        return loss
+
+
+def _rows2d(log_qy):
+    if log_qy.dim() > 2:
+        log_qy = log_qy.squeeze()                                  # criterions.py:101-102, 140-141
+    if log_qy.dim() != 2:
+        raise ValueError("expected [rows, k] log-probabilities, got shape %s" % (tuple(log_qy.shape),))
+    return log_qy
+
+
+def _row_average(R, batch_size, unit_average):
+    if unit_average:
+        return 1.0 / R                                             # torch.mean over rows
+    if batch_size is None:
+        raise TypeError("batch_size is required when unit_average=False")
+    return 1.0 / float(batch_size)
 
 
 class CatKLLoss(_Loss):
-    """sum_k q (log q - log p) per row (criterions.py:93-109); tiny, kept on stock tensor ops."""
+    """sum_k q (log q - log p) per row, then mean over rows or sum / batch_size (criterions.py:93-109), on the
+    wavefront row-reduction kernel `laed_cat_rows_fwd/bwd`.  log_py: 1-element, [k], [1,k], [R,1] or [R,k]."""
 
     def forward(self, log_qy, log_py, batch_size=None, unit_average=False):
-        if log_qy.dim() > 2:
-            log_qy = log_qy.squeeze()
-        qy = torch.exp(log_qy)
-        y_kl = torch.sum(qy * (log_qy - log_py), dim=1)
-        return torch.mean(y_kl) if unit_average else torch.sum(y_kl) / batch_size
+        log_qy = _rows2d(log_qy)
+        return ops.CatRowsFunction.apply(log_qy, log_py, _row_average(log_qy.shape[0], batch_size, unit_average))
 
 
 class Entropy(_Loss):
-    """-sum_k q log q per row (criterions.py:132-147)."""
+    """-sum_k q log q per row (criterions.py:132-147), same kernel with no prior."""
 
     def forward(self, log_qy, batch_size=None, unit_average=False):
-        if log_qy.dim() > 2:
-            log_qy = log_qy.squeeze()
-        qy = torch.exp(log_qy)
-        h_q = torch.sum(-1 * log_qy * qy, dim=1)
-        return torch.mean(h_q) if unit_average else torch.sum(h_q) / batch_size
+        log_qy = _rows2d(log_qy)
+        return ops.CatRowsFunction.apply(log_qy, None, _row_average(log_qy.shape[0], batch_size, unit_average))
 
 
 class BatchPriorKL(_Loss):

@@ -368,6 +368,86 @@ class LatentLossFunction(torch.autograd.Function):
         return dlq, None, None, None
 
 
+class CatRowsFunction(torch.autograd.Function):
+    """CatKLLoss / Entropy on arbitrary rows: log_qy[R,k] (, log_py 1-element | [k] | [1,k] | [R,1] | [R,k]) ->
+    scale * sum_r row_r, row_r = sum_c q (lq - lp)  (log_py None: sum_c -lq q).  criterions.py:97-109, 136-147."""
+
+    @staticmethod
+    def forward(ctx, log_qy, log_py, scale):
+        log_qy = _f32c(log_qy)
+        ptr(log_qy)                                           # refuses CPU tensors before any device call
+        R, k = log_qy.shape
+        dev = log_qy.device
+        py_rows, py_cols = 1, 1
+        if log_py is not None:
+            log_py = _f32c(log_py)
+            shp = tuple(log_py.shape)
+            if log_py.numel() == 1:
+                py_rows, py_cols = 1, 1
+            elif shp in ((k,), (1, k)):
+                py_rows, py_cols = 1, k
+            elif shp == (R, 1):
+                py_rows, py_cols = R, 1
+            elif shp == (R, k):
+                py_rows, py_cols = R, k
+            else:
+                raise _lib.LaedError("CatKLLoss: log_py of shape %s does not broadcast to log_qy %s" % (shp, (R, k)))
+        if ctx.needs_input_grad[1] and (py_rows, py_cols) != (R, k):
+            raise NotImplementedError("CatKLLoss: a broadcast log_py that requires grad is not supported "
+                                      "(the reference only trains full-shape priors)")
+        part = workspace("cat_rows", int(lib.laed_cat_rows_blocks()), dev)
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        check(lib.laed_cat_rows_fwd(ptr(log_qy), ptr(log_py), py_rows, py_cols, R, k, float(scale), None, ptr(part),
+                                    ptr(out), stream()), "laed_cat_rows_fwd")
+        ctx.save_for_backward(log_qy, log_py)
+        ctx.meta = (py_rows, py_cols, float(scale))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        log_qy, log_py = ctx.saved_tensors
+        py_rows, py_cols, scale = ctx.meta
+        R, k = log_qy.shape
+        g = _f32c(dout).reshape(1)
+        dlq = torch.empty_like(log_qy) if ctx.needs_input_grad[0] else None
+        dlp = torch.empty_like(log_qy) if ctx.needs_input_grad[1] else None
+        if dlq is not None or dlp is not None:
+            check(lib.laed_cat_rows_bwd(ptr(log_qy), ptr(log_py), py_rows, py_cols, R, k, ptr(g), scale, ptr(dlq), ptr(dlp),
+                                        stream()), "laed_cat_rows_bwd")
+        if dlp is not None:
+            dlp = dlp.view(log_py.shape)
+        return dlq, dlp, None
+
+
+class NLLGatherFunction(torch.autograd.Function):
+    """Dense log-probs logp[N,V], labels[N], row_scale[N] -> (sum_r row_scale[r]*tok_nll[r], tok_nll[N]) with
+    tok_nll[r] = -logp[r, labels[r]] on non-PAD rows (criterions.py:43-72 on a materialised tensor)."""
+
+    @staticmethod
+    def forward(ctx, logp, labels, row_scale, pad_id):
+        logp = _f32c(logp)
+        N, V = logp.shape
+        tok = torch.empty(N, device=logp.device, dtype=torch.float32)
+        check(lib.laed_nll_gather_fwd(ptr(logp), V, ptr(labels, I64), N, V, int(pad_id), ptr(tok), stream()),
+              "laed_nll_gather_fwd")
+        loss = torch.empty(1, device=logp.device, dtype=torch.float32)
+        check(lib.laed_dot(ptr(tok), ptr(row_scale), N, ptr(loss), stream()), "laed_dot")
+        ctx.save_for_backward(labels, row_scale)
+        ctx.meta = (N, V, int(pad_id))
+        ctx.mark_non_differentiable(tok)
+        return loss[0], tok
+
+    @staticmethod
+    def backward(ctx, dloss, _dtok):
+        labels, row_scale = ctx.saved_tensors
+        N, V, pad_id = ctx.meta
+        g = _f32c(dloss).reshape(1)
+        dlogp = torch.empty((N, V), device=labels.device, dtype=torch.float32)
+        check(lib.laed_nll_gather_bwd(ptr(labels, I64), ptr(row_scale), ptr(g), N, V, pad_id, ptr(dlogp), V, stream()),
+              "laed_nll_gather_bwd")
+        return dlogp, None, None, None
+
+
 class ProjNLLFunction(torch.autograd.Function):
     """h[N,H], W[V,H], b[V], labels[N], row_scale[N] -> (loss = sum_r row_scale[r]*nll[r], tok_nll[N]).
 

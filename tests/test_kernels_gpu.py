@@ -239,6 +239,96 @@ def test_latent_losses(ops, O):
             assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5
 
 
+def test_nll_entropy_dense_input(ops, O):
+    """NLLEntropy handed a materialised log-prob tensor (criterions.py:43-72): the reference's golden vectors for the
+    four averaging modes, then values and the scatter gradient vs the oracle (ignore index 0 and -100)."""
+    from argparse import Namespace
+    from helpers import load_golden
+    from laed_amd import criterions
+    G = load_golden("modules")
+    logp, labels = torch.from_numpy(G["nll/logp"]), torch.from_numpy(G["nll/labels"])
+    for avg in (None, "seq", "real_word", "word"):
+        crit = criterions.NLLEntropy(0, Namespace(avg_type=avg))
+        assert abs(float(crit(dev(logp), dev(labels))) - float(G["nll/out_%s" % avg])) < 1e-5, avg
+    gen = torch.Generator().manual_seed(11)
+    for (B, T, V) in ((1, 1, 3), (5, 7, 33), (30, 39, 1003)):
+        logp = torch.log_softmax(rnd(B, T, V, seed=B, scale=2.0), dim=2)
+        labels = torch.randint(1, V, (B, T), generator=gen)
+        labels[B // 2, T // 2:] = 0                                        # a PAD tail
+        labels[:, 0] = torch.randint(1, V, (B,), generator=gen)            # every row keeps one word ('real_word')
+        for avg in (None, "seq", "real_word", "word"):
+            lc = logp.clone().requires_grad_(True)
+            ref = O.nll_entropy(lc, labels, avg)
+            (ref * 1.1).backward()
+            lg = dev(logp).requires_grad_(True)
+            out = criterions.NLLEntropy(0, Namespace(avg_type=avg))(lg, dev(labels))
+            assert abs(float(out) - float(ref)) <= 1e-6 + 1e-5 * abs(float(ref)), (B, T, V, avg)
+            (out * 1.1).backward()
+            assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5, (B, T, V, avg)
+    # ignore index -100 (the attribute loss of dialog_models.py): every label counts, id 0 included
+    logp = torch.log_softmax(rnd(4, 6, 9, seed=3), dim=2)
+    labels = torch.randint(0, 9, (4, 6), generator=gen)
+    ref = torch.nn.functional.nll_loss(logp.view(-1, 9), labels.view(-1), ignore_index=-100)
+    out = criterions.NLLEntropy(-100, Namespace(avg_type="word"))(dev(logp), dev(labels))
+    assert abs(float(out) - float(ref)) < 1e-5
+    bad = labels.clone()
+    bad[0, 0] = 9                                                          # out of range: NaN, never a silent value
+    assert np.isnan(float(criterions.NLLEntropy(-100, Namespace(avg_type="word"))(dev(logp), dev(bad))))
+
+
+def test_cat_kl_and_entropy_modules(ops, O):
+    """criterions.CatKLLoss / Entropy (the general modules, laed/criterions.py:93-109, 132-147) on the row kernels:
+    the reference's golden vectors, then every log_py broadcast the reference uses, values and gradients vs the oracle."""
+    from helpers import load_golden
+    from laed_amd import criterions
+    G = load_golden("modules")
+    kl, ent = criterions.CatKLLoss(), criterions.Entropy()
+    lq, lp = torch.from_numpy(G["catkl/log_qy"]), torch.from_numpy(G["catkl/log_py"])
+    assert abs(float(kl(dev(lq), dev(lp), 4, True)) - float(G["catkl/unit"])) < 1e-6
+    assert abs(float(kl(dev(lq), dev(lp), 4, False)) - float(G["catkl/batch"])) < 1e-6
+    assert abs(float(ent(dev(lq), None, True)) - float(G["entropy/unit"])) < 1e-6
+    assert abs(float(ent(dev(lq), 4, False)) - float(G["entropy/batch"])) < 1e-6
+
+    for (R, k, seed) in ((1, 3, 1), (20, 10, 2), (600, 10, 3), (70001, 10, 4), (37, 40, 5), (9, 64, 6)):
+        log_qy = torch.log_softmax(rnd(R, k, seed=seed, scale=3.0), dim=1)
+        priors = {"uniform1": torch.log(torch.ones(1) / k),                       # sent_models.py:81
+                  "row": torch.log_softmax(rnd(k, seed=seed + 7), dim=0),
+                  "row2d": torch.log_softmax(rnd(1, k, seed=seed + 8), dim=1),
+                  "full": torch.log_softmax(rnd(R, k, seed=seed + 9, scale=2.0), dim=1)}
+        for name, log_py in priors.items():
+            for unit in (True, False):
+                py_grad = name == "full"
+                qc, pc = log_qy.clone().requires_grad_(True), log_py.clone().requires_grad_(py_grad)
+                ref = O.cat_kl(qc, pc, 7, unit)
+                (ref * 1.3).backward()
+                qg, pg = dev(log_qy).requires_grad_(True), dev(log_py).requires_grad_(py_grad)
+                out = kl(qg, pg, 7, unit)
+                assert abs(float(out) - float(ref)) <= 1e-6 + 2e-5 * abs(float(ref)), (R, k, name, unit)
+                (out * 1.3).backward()
+                assert rel_err(qg.grad.cpu(), qc.grad) < 1e-5, (R, k, name, unit)
+                if py_grad:
+                    assert rel_err(pg.grad.cpu(), pc.grad) < 1e-5
+        for unit in (True, False):
+            qc = log_qy.clone().requires_grad_(True)
+            ref = O.entropy(qc, 5, unit)
+            (ref * 0.7).backward()
+            qg = dev(log_qy).requires_grad_(True)
+            out = ent(qg.view(R, 1, k) if R > 1 else qg, 5, unit)                 # the dim > 2 squeeze of criterions.py:140
+            assert abs(float(out) - float(ref)) <= 1e-6 + 2e-5 * abs(float(ref)), (R, k, unit)
+            (out * 0.7).backward()
+            assert rel_err(qg.grad.cpu(), qc.grad) < 1e-5
+    # detached posterior (dialog_models.py: pi_kl): only the prior receives a gradient
+    qg, pg = dev(log_qy), dev(priors["full"]).requires_grad_(True)
+    kl(qg, pg, None, True).backward()
+    assert rel_err(pg.grad.cpu(), -torch.exp(log_qy) / log_qy.shape[0]) < 1e-5
+    a = kl(dev(log_qy), dev(priors["full"]), None, True)
+    assert float(a) == float(kl(dev(log_qy), dev(priors["full"]), None, True))    # fixed-order reduction
+    with pytest.raises(Exception):
+        kl(dev(log_qy), dev(torch.zeros(3, log_qy.shape[1])), None, True)        # does not broadcast
+    with pytest.raises(TypeError):
+        kl(dev(log_qy), dev(priors["full"]))                                      # batch_size missing, as sum / None raises
+
+
 @pytest.mark.parametrize("N,H,V,chunk", [(48, 32, 50, None), (100, 64, 401, 32), (1170, 128, 1003, 512), (300, 96, 2050, 128)])
 def test_proj_nll(ops, N, H, V, chunk):
     h, W, b = rnd(N, H, seed=1), rnd(V, H, seed=2, scale=0.3), rnd(V, seed=3, scale=0.1)

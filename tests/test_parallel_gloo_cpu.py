@@ -54,10 +54,13 @@ def _worker(rank, world, port, result_dir):
     u = G["in/u_steps"][0][b0 * y:b1 * y]
     with torch.no_grad():
         res = O.divae_forward(P, cfg, G["in/outputs"][b0:b1], u, training=True)
-    # 'word' NLL through the product's criterion (dense path): global count via all-reduce
+    # 'word' NLL: the product criterion's row weights (1 / GLOBAL non-PAD count, via its all-reduce) applied to the
+    # oracle's per-token NLL of this shard (the criterion's arithmetic itself only exists on the GPU)
     labels = torch.from_numpy(G["in/outputs"][b0:b1, 1:].astype(np.int64))
     crit = criterions.NLLEntropy(0, Namespace(avg_type="word", use_gpu=False))
-    nll_share = crit(res["logp"], labels).reshape(1)
+    scale = crit._row_scale(labels, labels.shape[0], labels.shape[1])
+    tok = -res["logp"].gather(2, labels.unsqueeze(2)).squeeze(2) * (labels != 0).float()
+    nll_share = (tok * scale).sum().reshape(1)
     dist.all_reduce(nll_share)
     assert abs(float(nll_share) - float(G["out/nll"])) < 1e-5 * abs(float(G["out/nll"]))
     # BPR: all-reduce sum_b q, then the finalize formulas (laed_latent_finalize restated)
