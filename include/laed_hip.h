@@ -231,6 +231,29 @@ int laed_nll_gather_bwd(const int64_t* labels, const float* row_scale, const flo
                         int64_t pad_id, float* dlogp, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Attention pooling of RnnUttEncoder (encoders.py:119-130: fc1 = tanh(key_w(enc_outs)); attn = softmax_t(query(fc1));
+ * utt_embedded = sum_t attn * enc_outs) around the two Linear layers, which run on laed_sgemm.
+ *   laed_attn_score_fwd: fc1[R][Hk] holds key_w's output on entry and tanh of it on return (kept for backward);
+ *                        score[r] = fc1[r] . wq + bq[0]   (query.weight [1][Hk], query.bias [1]; bq may be NULL)
+ *   laed_attn_pool_fwd:  attn[N][T] = softmax over t of score[n*s_sn + t*s_st];  out[N][D] = sum_t attn * enc,
+ *                        enc element (n,t,d) at enc[n*e_sn + t*e_st + d]  (T <= 1024): the GRU's time-major output is
+ *                        read in place (e_sn = D, e_st = N*D)
+ *   laed_attn_pool_bwd:  dscore (same strides as score) and, if denc != NULL, denc[n*g_sn + t*g_st + d] = attn*dout
+ *   laed_attn_score_bwd: dpre[r][j] = dscore[r] wq[j] (1 - fc1^2)  (d wq = dscore^T fc1 and d bq = sum dscore are a
+ *                        laed_sgemm_ws call with transA and its column sum)
+ * laed_tanh_fwd/bwd: the tanh between p_fc1 and p_y in the prior network (dialog_models.py:243, :513).
+ * ------------------------------------------------------------------------------------------ */
+int laed_attn_score_fwd(float* fc1, const float* wq, const float* bq, int64_t R, int Hk, float* score, void* stream);
+int laed_attn_score_bwd(const float* fc1, const float* dscore, const float* wq, int64_t R, int Hk, float* dpre, void* stream);
+int laed_attn_pool_fwd(const float* score, int64_t s_sn, int64_t s_st, const float* enc, int64_t e_sn, int64_t e_st,
+                       int64_t N, int T, int D, float* attn, float* out, void* stream);
+int laed_attn_pool_bwd(const float* enc, int64_t e_sn, int64_t e_st, const float* attn, const float* dout,
+                       int64_t N, int T, int D, float* dscore, int64_t s_sn, int64_t s_st,
+                       float* denc, int64_t g_sn, int64_t g_st, void* stream);
+int laed_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int laed_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam defaults; model_bases.py:122-125): in place on p, m, v.  `step` is 1-based.
  * grad_scale multiplies g first (1/world_size after a sum all-reduce).
  * ------------------------------------------------------------------------------------------ */

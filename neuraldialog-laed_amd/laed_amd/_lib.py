@@ -56,6 +56,12 @@ _SIGS = {
     "laed_nll_reduce": ([_p, _p, _i64, _i64, _p, _p], _i),
     "laed_nll_gather_fwd": ([_p, _i64, _p, _i64, _i, _i64, _p, _p], _i),
     "laed_nll_gather_bwd": ([_p, _p, _p, _i64, _i, _i64, _p, _i64, _p], _i),
+    "laed_attn_score_fwd": ([_p, _p, _p, _i64, _i, _p, _p], _i),
+    "laed_attn_score_bwd": ([_p, _p, _p, _i64, _i, _p, _p], _i),
+    "laed_attn_pool_fwd": ([_p, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _p, _p, _p], _i),
+    "laed_attn_pool_bwd": ([_p, _i64, _i64, _p, _p, _i64, _i, _i, _p, _i64, _i64, _p, _i64, _i64, _p], _i),
+    "laed_tanh_fwd": ([_p, _p, _i64, _p], _i),
+    "laed_tanh_bwd": ([_p, _p, _p, _i64, _p], _i),
     "laed_adam_step": ([_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _f, _p], _i),
     "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),
     "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),

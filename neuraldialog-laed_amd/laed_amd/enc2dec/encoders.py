@@ -2,6 +2,7 @@
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..nn_lib import Embedding, Linear
 from .base_modules import BaseRNN
 
@@ -60,10 +61,9 @@ class RnnUttEncoder(nn.Module):
             words_embeded = torch.cat([words_embeded, flat_feats], dim=2)
         enc_outs, enc_last = self.rnn(words_embeded, init_state=init_state)
         if self.use_attn:
-            fc1 = torch.tanh(self.key_w(enc_outs))
-            attn = self.query(fc1).squeeze(2)
-            attn = torch.softmax(attn, attn.dim() - 1).unsqueeze(2)
-            utt_embedded = torch.sum(attn * enc_outs, dim=1)
+            # tanh(key_w(.)) -> query -> softmax over positions -> weighted sum (encoders.py:119-130), HIP kernels
+            utt_embedded, attn = ops.attn_pool(enc_outs, self.key_w, self.query)
+            attn = attn.unsqueeze(2)
         else:
             attn = None
             utt_embedded = enc_last.transpose(0, 1).contiguous().view(-1, self.output_size)

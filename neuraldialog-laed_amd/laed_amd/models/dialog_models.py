@@ -25,7 +25,9 @@ from .model_bases import BaseModel
 
 def _mean_ce(log_p, ids):
     """F.cross_entropy(logits, ids) given log_p = log_softmax(logits): mean_r -log_p[r, ids[r]] (tiny [B*y,k])."""
-    return -log_p.gather(1, ids.reshape(-1, 1)).mean()
+    R = log_p.shape[0]
+    scale = torch.full((R,), 1.0 / R, device=log_p.device)
+    return ops.NLLGatherFunction.apply(log_p, ids.reshape(-1).contiguous(), scale, -100)[0]
 
 
 def _err_rate(logits, ids):
@@ -105,7 +107,7 @@ class LAED(BaseModel):
         c_inputs = self.utt_encoder(ctx_utts)
         c_outs, c_last = self.ctx_encoder(c_inputs, ctx_lens)
         c_last = c_last.squeeze(0)
-        hid = torch.tanh(self.p_fc1(c_last)) if with_fc1 else c_last
+        hid = ops.tanh(self.p_fc1(c_last)) if with_fc1 else c_last
         py_logits = self.p_y(hid).view(-1, self.config.k)
         log_py = ops.LogSoftmaxKFunction.apply(py_logits)
         return c_outs, c_last, py_logits, log_py

@@ -448,6 +448,108 @@ class NLLGatherFunction(torch.autograd.Function):
         return dlogp, None, None, None
 
 
+class TanhFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        check(lib.laed_tanh_fwd(ptr(x), ptr(y), x.numel(), stream()), "laed_tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        check(lib.laed_tanh_bwd(ptr(y), ptr(_f32c(dy)), ptr(dx), y.numel(), stream()), "laed_tanh_bwd")
+        return dx
+
+
+def tanh(x):
+    return TanhFunction.apply(x)
+
+
+def _nt_strides(t3):
+    """(utterance stride, position stride) of a [N,T,D] tensor whose last dimension is dense; the tensor itself when
+    it is batch-first contiguous or a batch-first view of time-major contiguous memory, else a contiguous copy."""
+    N, T, D = t3.shape
+    if t3.stride(2) == 1 or D == 1:
+        if t3.is_contiguous():
+            return t3, T * D, D
+        if t3.transpose(0, 1).is_contiguous():
+            return t3, D, N * D
+    t3 = t3.contiguous()
+    return t3, T * D, D
+
+
+class AttnPoolFunction(torch.autograd.Function):
+    """enc[N,T,D], pre = key_w(enc) as rows [R,Hk] in the SAME (utterance, position) memory order as enc, query weight
+    wq[1,Hk] and bias bq[1] -> (pooled[N,D], attn[N,T]).  encoders.py:119-130 minus the key_w GEMM, which stays a
+    LinearFunction node in front of this one (its backward turns d pre into d enc and d key_w)."""
+
+    @staticmethod
+    def forward(ctx, enc, pre, wq, bq, time_major):
+        N, T, D = enc.shape
+        Hk = pre.shape[1]
+        dev = enc.device
+        fc1 = _f32c(pre).clone()                          # tanh in place; `pre` belongs to the GEMM node
+        score = torch.empty(N * T, device=dev, dtype=torch.float32)
+        check(lib.laed_attn_score_fwd(ptr(fc1), ptr(wq), ptr(bq), N * T, Hk, ptr(score), stream()), "laed_attn_score_fwd")
+        s_sn, s_st = (1, N) if time_major else (T, 1)
+        e_sn, e_st = (D, N * D) if time_major else (T * D, D)
+        attn = torch.empty((N, T), device=dev, dtype=torch.float32)
+        out = torch.empty((N, D), device=dev, dtype=torch.float32)
+        check(lib.laed_attn_pool_fwd(ptr(score), s_sn, s_st, ctypes_ptr(enc), e_sn, e_st, N, T, D, ptr(attn), ptr(out), stream()),
+              "laed_attn_pool_fwd")
+        ctx.save_for_backward(enc, fc1, wq, attn)
+        ctx.meta = (bool(time_major), bq is not None)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, _dattn):
+        enc, fc1, wq, attn = ctx.saved_tensors
+        time_major, has_bq = ctx.meta
+        N, T, D = enc.shape
+        R, Hk = fc1.shape
+        dev = enc.device
+        s_sn, s_st = (1, N) if time_major else (T, 1)
+        e_sn, e_st = (D, N * D) if time_major else (T * D, D)
+        dscore = torch.empty(R, device=dev, dtype=torch.float32)
+        denc = None
+        if ctx.needs_input_grad[0]:                       # same memory order as enc
+            denc = torch.empty((T, N, D) if time_major else (N, T, D), device=dev, dtype=torch.float32)
+        check(lib.laed_attn_pool_bwd(ctypes_ptr(enc), e_sn, e_st, ptr(attn), ptr(_f32c(dout)), N, T, D, ptr(dscore), s_sn, s_st,
+                                     ptr(denc), e_sn, e_st, stream()), "laed_attn_pool_bwd")
+        dpre = torch.empty_like(fc1)
+        check(lib.laed_attn_score_bwd(ptr(fc1), ptr(dscore), ptr(wq), R, Hk, ptr(dpre), stream()), "laed_attn_score_bwd")
+        dbq = torch.empty(1, device=dev, dtype=torch.float32) if has_bq else None
+        dwq = sgemm(dscore.view(R, 1), fc1, transA=True, colsum_out=dbq)      # [1,Hk] = dscore^T fc1; db = sum dscore
+        if denc is not None and time_major:
+            denc = denc.transpose(0, 1)
+        return denc, dpre, dwq, dbq, None
+
+
+def ctypes_ptr(t):
+    """Device pointer of a dense-last-dim CUDA fp32 tensor addressed with explicit strides by the callee."""
+    import ctypes
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.LaedError("laed_amd kernels need fp32 CUDA (ROCm) tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def attn_pool(enc_outs, key_w, query):
+    """RnnUttEncoder's attention pooling: enc_outs [N,T,D] -> (utt_embedded [N,D], attn [N,T])."""
+    if not enc_outs.is_cuda:
+        raise _lib.LaedError("laed_amd kernels need CUDA (ROCm) tensors; got a CPU tensor")
+    enc, e_sn, e_st = _nt_strides(_f32c(enc_outs) if enc_outs.dtype != torch.float32 else enc_outs)
+    N, T, D = enc.shape
+    time_major = (e_sn, e_st) == (D, N * D) and N > 1
+    rows = enc.transpose(0, 1).reshape(T * N, D) if time_major else enc.reshape(N * T, D)      # views, no copy
+    pre = linear(rows, key_w.weight, key_w.bias)
+    return AttnPoolFunction.apply(enc, pre, query.weight, query.bias, time_major)
+
+
 class ProjNLLFunction(torch.autograd.Function):
     """h[N,H], W[V,H], b[V], labels[N], row_scale[N] -> (loss = sum_r row_scale[r]*nll[r], tok_nll[N]).
 

@@ -25,6 +25,10 @@ def _free_port():
 
 
 def _worker(rank, world, port, result_dir):
+    import faulthandler
+    # a rank that is still running after 100 s dumps every thread's stack and exits: the test then fails with the
+    # place it was stuck at instead of hanging until the runner's own time limit
+    faulthandler.dump_traceback_later(100, exit=True)
     for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -75,6 +79,7 @@ def _worker(rank, world, port, result_dir):
         assert float((p.detach().cpu() - torch.from_numpy(G["p1/" + n])).abs().max()) < 1e-4, n
     dist.destroy_process_group()
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
+    faulthandler.cancel_dump_traceback_later()
 
 
 @pytest.mark.parametrize("world", [2, 4])

@@ -239,6 +239,53 @@ def test_latent_losses(ops, O):
             assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5
 
 
+def test_attn_pool_and_tanh(ops):
+    """RnnUttEncoder's attention pooling (encoders.py:119-130) and the prior network's tanh on their kernels, values
+    and every gradient vs the same op sequence in torch CPU fp32; batch-first and time-major encoder memory."""
+    from laed_amd.nn_lib import Linear
+    for (N, T, D, Hk, seed) in ((1, 1, 8, 4, 1), (6, 9, 64, 32, 2), (40, 37, 200, 100, 3), (3, 130, 20, 7, 4)):
+        torch.manual_seed(seed)
+        key_c, query_c = torch.nn.Linear(D, Hk), torch.nn.Linear(Hk, 1)
+        key_g, query_g = Linear(D, Hk), Linear(Hk, 1)
+        key_g.load_state_dict(key_c.state_dict())
+        query_g.load_state_dict(query_c.state_dict())
+        key_g.cuda()
+        query_g.cuda()
+        enc = rnd(N, T, D, seed=seed)
+        w = rnd(N, D, seed=seed + 1)
+        for time_major in (False, True):
+            for m in (key_c, query_c, key_g, query_g):
+                m.zero_grad()
+            ec = enc.clone().requires_grad_(True)
+            fc1 = torch.tanh(key_c(ec))
+            a_c = torch.softmax(query_c(fc1).squeeze(2), 1).unsqueeze(2)
+            out_c = torch.sum(a_c * ec, dim=1)
+            ((out_c * w).sum() + 0.3 * (ec * ec).sum()).backward()
+            if time_major:
+                leaf = dev(enc.transpose(0, 1).contiguous()).requires_grad_(True)      # [T,N,D] memory
+                eg = leaf.transpose(0, 1)
+            else:
+                leaf = dev(enc).requires_grad_(True)
+                eg = leaf
+            out_g, a_g = ops.attn_pool(eg, key_g, query_g)
+            assert rel_err(out_g.detach().cpu(), out_c.detach()) < 1e-5, (N, T, D, Hk, time_major)
+            assert rel_err(a_g.cpu(), a_c.detach().squeeze(2)) < 1e-5
+            ((out_g * dev(w)).sum() + 0.3 * (eg * eg).sum()).backward()
+            g = leaf.grad.transpose(0, 1) if time_major else leaf.grad
+            assert rel_err(g.cpu(), ec.grad) < 2e-5, (N, T, D, Hk, time_major)
+            for mc, mg in ((key_c, key_g), (query_c, query_g)):
+                assert rel_err(mg.weight.grad.cpu(), mc.weight.grad) < 5e-5, (N, T, D, Hk, time_major)
+                assert float((mg.bias.grad.cpu() - mc.bias.grad).abs().max()) < 1e-5 * max(1.0, float(mc.weight.grad.abs().max()))
+    x = rnd(37, 53, seed=9, scale=3.0)
+    xc, xg = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+    wgt = rnd(37, 53, seed=10)
+    (torch.tanh(xc) * wgt).sum().backward()
+    y = ops.tanh(xg)
+    assert rel_err(y.detach().cpu(), torch.tanh(x)) < 1e-6
+    (y * dev(wgt)).sum().backward()
+    assert rel_err(xg.grad.cpu(), xc.grad) < 1e-5
+
+
 def test_nll_entropy_dense_input(ops, O):
     """NLLEntropy handed a materialised log-prob tensor (criterions.py:43-72): the reference's golden vectors for the
     four averaging modes, then values and the scatter gradient vs the oracle (ignore index 0 and -100)."""
