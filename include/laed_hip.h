@@ -135,6 +135,14 @@ int laed_latent_finalize(const float* stats, double B_global, int y, int k, floa
 int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale, int use_mutual,
                     int64_t B, double B_global, int y, int k, float* dlog_qy, int accumulate, void* stream);
 
+/* The batch-mean posterior as a tensor of its own, for the train_prior branch (sent_models.py:138-139, 144-146):
+ *   laed_avg_log_fwd:  avg_log[e] = log(stats[e] / B_global + 1e-15), e < n = y*k, stats from laed_latent_stats
+ *                      (all-reduced under data parallelism)
+ *   laed_avg_log_coef: coef[e] = davg_log[e] / (stats[e]/B_global + 1e-15) / B_global; then
+ *                      laed_latent_bwd(use_mutual = 1, gscale = NULL) gives d log_qy = coef .* q */
+int laed_avg_log_fwd(const float* stats, double B_global, int n, float* avg_log, void* stream);
+int laed_avg_log_coef(const float* stats, const float* davg_log, double B_global, int n, float* coef, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CatKLLoss / Entropy on arbitrary rows (the general criterions, outside the fused block above).
  * Replaces criterions.py:97-109 (CatKLLoss.forward: sum_k exp(lq) (lq - lp) per row, then mean over rows or

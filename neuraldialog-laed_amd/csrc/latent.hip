@@ -272,6 +272,18 @@ __global__ __launch_bounds__(256) void cat_rows_bwd_kernel(const float* __restri
     }
 }
 
+// avg_log_qy = log(mean_b q + 1e-15) as a tensor of its own (sent_models.py:138-139), for the train_prior branch
+// (:144-146) where it meets a learned prior in CatKLLoss.  stats = sum_b q (laed_latent_stats, all-reduced).
+__global__ __launch_bounds__(256) void avg_log_fwd_kernel(const float* __restrict__ stats, float Bg, int n, float* __restrict__ out) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) out[e] = logf(stats[e] / Bg + 1e-15f);
+}
+// coef[e] = d out[e] / d q[b][e] * dav[e] = dav[e] / (qbar + 1e-15) / Bg;  d log_qy = coef .* q  (laed_latent_bwd)
+__global__ __launch_bounds__(256) void avg_log_coef_kernel(const float* __restrict__ stats, const float* __restrict__ dav, float Bg,
+                                                           int n, float* __restrict__ coef) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x)
+        coef[e] = dav[e] / (stats[e] / Bg + 1e-15f) / Bg;
+}
+
 }   // namespace
 
 #define DISPATCH_W(k, CALL)                         \
@@ -379,5 +391,21 @@ extern "C" int laed_cat_rows_bwd(const float* log_qy, const float* log_py, int64
     hipLaunchKernelGGL(cat_rows_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, log_py, py_rows, py_cols, R, k,
                        gscale, scale, dlog_qy, dlog_py);
     LAED_LAUNCH_CHECK("cat_rows_bwd");
+    return 0;
+}
+
+extern "C" int laed_avg_log_fwd(const float* stats, double B_global, int n, float* avg_log, void* stream) {
+    LAED_CHECK_ARG(B_global > 0 && n > 0, "avg_log_fwd: bad size");
+    LAED_CHECK_ARG(stats && avg_log, "avg_log_fwd: null pointer");
+    hipLaunchKernelGGL(avg_log_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (float)B_global, n, avg_log);
+    LAED_LAUNCH_CHECK("avg_log_fwd");
+    return 0;
+}
+
+extern "C" int laed_avg_log_coef(const float* stats, const float* davg_log, double B_global, int n, float* coef, void* stream) {
+    LAED_CHECK_ARG(B_global > 0 && n > 0, "avg_log_coef: bad size");
+    LAED_CHECK_ARG(stats && davg_log && coef, "avg_log_coef: null pointer");
+    hipLaunchKernelGGL(avg_log_coef_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, davg_log, (float)B_global, n, coef);
+    LAED_LAUNCH_CHECK("avg_log_coef");
     return 0;
 }

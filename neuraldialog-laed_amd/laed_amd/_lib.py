@@ -42,6 +42,8 @@ _SIGS = {
     "laed_latent_stats": ([_p, _i64, _i, _i, _p, _p, _p], _i),
     "laed_latent_finalize": ([_p, _d, _i, _i, _p, _p, _p], _i),
     "laed_latent_bwd": ([_p, _p, _p, _i, _i64, _d, _i, _i, _p, _i, _p], _i),
+    "laed_avg_log_fwd": ([_p, _d, _i, _p, _p], _i),
+    "laed_avg_log_coef": ([_p, _p, _d, _i, _p, _p], _i),
     "laed_cat_rows_blocks": ([], _i),
     "laed_cat_rows_fwd": ([_p, _p, _i64, _i, _i64, _i, _f, _p, _p, _p, _p], _i),
     "laed_cat_rows_bwd": ([_p, _p, _i64, _i, _i64, _i, _p, _f, _p, _p, _p], _i),

@@ -93,15 +93,23 @@ class Entropy(_Loss):
 
 
 class BatchPriorKL(_Loss):
-    """The fused BPR / reg_kl / MI block of sent_models.py:138-156 (train_prior=False):
-    (reg_kl, b_pr, mi) from log_qy [B*y,k]; batch statistics all-reduced across the DP group."""
+    """The fused BPR / reg_kl / MI block of sent_models.py:138-156: (reg_kl, b_pr, mi) from log_qy [B*y,k]; batch
+    statistics all-reduced across the DP group.  With a learned prior `log_py` [y,k] (train_prior, :144-146) reg_kl is
+    KL(avg q || softmax(log_py)) through the general CatKLLoss kernel; b_pr and mi still come from the fused block."""
 
     def __init__(self, y_size, k, use_mutual=True):
         super(BatchPriorKL, self).__init__()
         self.y_size, self.k, self.use_mutual = y_size, k, use_mutual
         self.log_uniform = math.log(1.0 / k)
+        self.cat_kl_loss = CatKLLoss()
 
-    def forward(self, log_qy):
+    def forward(self, log_qy, log_py=None):
         b_pr, mi, row_kl = ops.LatentLossFunction.apply(log_qy, self.y_size, self.k, parallel.group())
-        reg_kl = b_pr if self.use_mutual else row_kl
+        if not self.use_mutual:
+            reg_kl = row_kl
+        elif log_py is not None:
+            avg_log_qy = ops.AvgLogQyFunction.apply(log_qy, self.y_size, self.k, parallel.group())
+            reg_kl = self.cat_kl_loss(avg_log_qy, ops.LogSoftmaxKFunction.apply(log_py), None, unit_average=True)
+        else:
+            reg_kl = b_pr
         return reg_kl, b_pr, mi.detach()

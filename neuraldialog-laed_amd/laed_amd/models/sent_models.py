@@ -83,8 +83,6 @@ class _SentBase(BaseModel):
 class DiVAE(_SentBase):
     def __init__(self, corpus, config):
         super(DiVAE, self).__init__(config)
-        if getattr(config, 'train_prior', False):
-            raise NotImplementedError("train_prior=True is off in ptb-utt.py's defaults and not built")
         self._build_common(corpus, config, connector_bias=False)
         self.decoder = self._make_decoder()
         self._build_losses(config)
@@ -111,7 +109,7 @@ class DiVAE(_SentBase):
             return dec_ctx, labels
         nll = self.nll_loss(dec_outs, labels)
         self._last_dec_outs = dec_outs
-        reg_kl, b_pr, mi = self.bpr_loss(log_qy)
+        reg_kl, b_pr, mi = self.bpr_loss(log_qy, self.log_py if getattr(self.config, 'train_prior', False) else None)
         results = Pack(nll=nll, reg_kl=reg_kl, mi=mi, bpr=b_pr)
         if return_latent:
             results['log_qy'] = log_qy

@@ -368,6 +368,43 @@ class LatentLossFunction(torch.autograd.Function):
         return dlq, None, None, None
 
 
+class AvgLogQyFunction(torch.autograd.Function):
+    """log_qy[B*y,k] -> avg_log_qy[y,k] = log(mean_b exp(log_qy) + 1e-15) (sent_models.py:138-139); the batch sum is
+    all-reduced over `group`, so every rank holds the global-batch value."""
+
+    @staticmethod
+    def forward(ctx, log_qy, y_size, k, group):
+        log_qy = _f32c(log_qy)
+        dev = log_qy.device
+        B = log_qy.shape[0] // y_size
+        n = y_size * k
+        nblk = int(lib.laed_latent_stats_blocks())
+        ws = workspace("latent", nblk * (n + 2), dev)
+        stats = torch.empty(n + 2, device=dev, dtype=torch.float32)
+        check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
+        Bg = float(B)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(stats, group=group)
+            Bg = float(B * dist.get_world_size(group))
+        avg = torch.empty((y_size, k), device=dev, dtype=torch.float32)
+        check(lib.laed_avg_log_fwd(ptr(stats), Bg, n, ptr(avg), stream()), "laed_avg_log_fwd")
+        ctx.save_for_backward(log_qy, stats)
+        ctx.meta = (B, Bg, y_size, k)
+        return avg
+
+    @staticmethod
+    def backward(ctx, davg):
+        log_qy, stats = ctx.saved_tensors
+        B, Bg, y_size, k = ctx.meta
+        coef = torch.empty(y_size * k, device=log_qy.device, dtype=torch.float32)
+        check(lib.laed_avg_log_coef(ptr(stats), ptr(_f32c(davg)), Bg, y_size * k, ptr(coef), stream()), "laed_avg_log_coef")
+        dlq = torch.empty_like(log_qy)
+        check(lib.laed_latent_bwd(ptr(log_qy), ptr(coef), None, 1, B, Bg, y_size, k, ptr(dlq), 0, stream()),
+              "laed_latent_bwd")
+        return dlq, None, None, None
+
+
 class CatRowsFunction(torch.autograd.Function):
     """CatKLLoss / Entropy on arbitrary rows: log_qy[R,k] (, log_py 1-element | [k] | [1,k] | [R,1] | [R,k]) ->
     scale * sum_r row_r, row_r = sum_c q (lq - lp)  (log_py None: sum_c -lq q).  criterions.py:97-109, 136-147."""

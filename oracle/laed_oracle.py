@@ -106,16 +106,23 @@ def entropy(log_qy, batch_size=None, unit_average=False):
     return h_q.mean() if unit_average else h_q.sum() / batch_size
 
 
-def latent_losses(log_qy, y_size, k, use_mutual=True):
-    """BPR / reg_kl / MI block, laed/models/sent_models.py:138-156 (train_prior=False).
+def latent_losses(log_qy, y_size, k, use_mutual=True, log_py=None):
+    """BPR / reg_kl / MI block, laed/models/sent_models.py:138-156.
 
-    log_qy [B*y,k].  Returns (reg_kl, bpr, mi).
+    log_qy [B*y,k].  log_py [y,k] (the model's `log_py` parameter) selects the train_prior branch (:144-146):
+    reg_kl = KL(avg q || softmax(log_py)).  Returns (reg_kl, bpr, mi).
     """
     log_uniform = math.log(1.0 / k)                                     # sent_models.py:81
     avg = torch.exp(log_qy.view(-1, y_size, k)).mean(dim=0)
     avg_log_qy = torch.log(avg + 1e-15)
     bpr = cat_kl(avg_log_qy, log_uniform, unit_average=True)
-    reg_kl = bpr if use_mutual else cat_kl(log_qy, log_uniform, unit_average=True)
+    if use_mutual:
+        if log_py is not None:
+            reg_kl = cat_kl(avg_log_qy, F.log_softmax(log_py, dim=log_py.dim() - 1), unit_average=True)
+        else:
+            reg_kl = bpr
+    else:
+        reg_kl = cat_kl(log_qy, log_uniform, unit_average=True)
     mi = entropy(avg_log_qy, unit_average=True) - entropy(log_qy, unit_average=True)
     return reg_kl, bpr, mi
 
@@ -209,7 +216,8 @@ def divae_forward(P, cfg, outputs, u, training=True, drop_mask=None):
     dm = None if (drop_mask is None or not training) else torch.as_tensor(drop_mask)
     logp, _ = decoder_teacher(P, 'decoder.', P['embedding.weight'], dec_inputs, dec_init, dm, cfg.dropout)
     nll = nll_entropy(logp, labels, cfg.avg_type)
-    reg_kl, bpr, mi = latent_losses(log_qy, cfg.y_size, cfg.k, cfg.use_mutual)
+    reg_kl, bpr, mi = latent_losses(log_qy, cfg.y_size, cfg.k, cfg.use_mutual,
+                                    P['log_py'] if getattr(cfg, 'train_prior', False) else None)
     total = nll + reg_kl if cfg.use_reg_kl else nll
     tok_nll = -logp.gather(2, labels.unsqueeze(2)).squeeze(2)
     return dict(nll=nll, reg_kl=reg_kl, mi=mi, bpr=bpr, log_qy=log_qy, y_ids=y_ids,
@@ -303,10 +311,10 @@ def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def trainable_keys(P):
-    """Parameters Adam updates: everything but the decoder.embedding alias; log_py gets no grad
-    (train_prior=False) and Adam skips grad-less params."""
-    return [k for k in P if not k.endswith('decoder.embedding.weight') and k != 'log_py']
+def trainable_keys(P, train_prior=False):
+    """Parameters Adam updates: everything but the decoder.embedding alias; log_py gets no grad unless
+    train_prior (sent_models.py:144-146) and Adam skips grad-less params."""
+    return [k for k in P if not k.endswith('decoder.embedding.weight') and (train_prior or k != 'log_py')]
 
 
 # --------------------------------------------------------------------------------------
@@ -362,5 +370,6 @@ class OracleDiVAE(nn.Module):
         logits = self.decoder.project(out.contiguous().view(-1, cfg.dec_cell_size))
         logp = F.log_softmax(logits, dim=1)
         nll = F.nll_loss(logp, labels.view(-1), ignore_index=PAD_ID)
-        reg_kl, bpr, mi = latent_losses(log_qy, cfg.y_size, cfg.k, cfg.use_mutual)
+        reg_kl, bpr, mi = latent_losses(log_qy, cfg.y_size, cfg.k, cfg.use_mutual,
+                                        self.log_py if getattr(cfg, 'train_prior', False) else None)
         return dict(nll=nll, reg_kl=reg_kl, mi=mi, bpr=bpr, total=nll + reg_kl)

@@ -117,6 +117,8 @@ def run_sent_model(kind, name, seed, V, B, T, cfg_kw, with_dropout_case):
     corpus = FakeCorpus(V)
     cls = sent_models.DiVAE if kind == 'divae' else sent_models.DiVST
     model = cls(corpus, config)
+    if cfg_kw.get('train_prior'):       # start from a non-uniform learned prior so that its gradient path is exercised
+        model.log_py.data.add_(torch.from_numpy(rs.normal(0.0, 0.5, size=tuple(model.log_py.shape)).astype(np.float32)))
     model.train()
     G = {}
     G['meta/torch_version'] = np.array(torch.__version__)
@@ -343,6 +345,13 @@ def run_modules(seed=7):
 if __name__ == '__main__':
     tiny = dict(embed_size=16, enc_cell_size=32, dec_cell_size=32, y_size=4, k=5, max_dec_len=10)
     mid = dict(embed_size=32, enc_cell_size=64, dec_cell_size=64, y_size=6, k=10, max_dec_len=12)
+    # the two non-default regularisers of sent_models.py:143-151: a trained prior, and the per-row KL
+    run_sent_model('divae', 'divae_tiny_prior', 15, V=50, B=6, T=8, cfg_kw=dict(tiny, train_prior=True),
+                   with_dropout_case=False)
+    run_sent_model('divae', 'divae_tiny_rowkl', 16, V=50, B=6, T=8, cfg_kw=dict(tiny, use_mutual=False),
+                   with_dropout_case=False)
+    if len(sys.argv) > 1 and sys.argv[1] == 'regularisers':
+        sys.exit(0)
     run_sent_model('divae', 'divae_tiny', 11, V=50, B=6, T=8, cfg_kw=tiny, with_dropout_case=True)
     run_sent_model('divae', 'divae_mid', 12, V=400, B=12, T=14, cfg_kw=mid, with_dropout_case=False)
     run_sent_model('divst', 'divst_tiny', 13, V=50, B=6, T=8, cfg_kw=tiny, with_dropout_case=True)

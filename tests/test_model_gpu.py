@@ -57,7 +57,7 @@ def close(a, b, rtol=LOSS_RTOL, atol=1e-7):
 
 
 @pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divae_mid", "divae"), ("divst_tiny", "divst"),
-                                       ("divst_mid", "divst")])
+                                       ("divst_mid", "divst"), ("divae_tiny_prior", "divae"), ("divae_tiny_rowkl", "divae")])
 def test_forward_backward_vs_reference(name, kind):
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     G = load_golden(name)
@@ -87,7 +87,8 @@ def test_forward_backward_vs_reference(name, kind):
             assert rel_err(p.grad.cpu(), g) < 2e-4, (n, rel_err(p.grad.cpu(), g))
 
 
-@pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst"), ("divae_mid", "divae")])
+@pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst"), ("divae_mid", "divae"),
+                                       ("divae_tiny_prior", "divae"), ("divae_tiny_rowkl", "divae")])
 def test_adam_steps_eval_and_greedy_vs_reference(name, kind):
     from laed_amd.enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
     G = load_golden(name)

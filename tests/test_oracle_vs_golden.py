@@ -10,8 +10,10 @@ from oracle import laed_oracle as O
 TOL = 2e-6   # same torch build, same arithmetic, different op grouping -> fp32 round-off only
 
 
-@pytest.mark.parametrize("name", ["divae_tiny", "divae_mid"])
+@pytest.mark.parametrize("name", ["divae_tiny", "divae_mid", "divae_tiny_prior", "divae_tiny_rowkl"])
 def test_divae_forward_backward(name):
+    """divae_tiny_prior: train_prior=True from a non-uniform log_py (sent_models.py:144-146); divae_tiny_rowkl:
+    use_mutual=False, the per-row KL of :150-151."""
     G = load_golden(name)
     cfg = golden_config(G)
     P = golden_params(G, requires_grad=True)
@@ -25,9 +27,12 @@ def test_divae_forward_backward(name):
     assert rel_err(res["tok_nll"].detach(), G["out/tok_nll"]) < 5e-6
     assert abs(float(res["total"]) - float(G["out/total_loss"])) < 1e-5
     res["total"].backward()
-    for k in O.trainable_keys(P):
+    for k in O.trainable_keys(P, bool(cfg.train_prior)):
         assert rel_err(P[k].grad, G["grad/" + k]) < 2e-5, k
-    assert G["grad/log_py"].size == 0 and P["log_py"].grad is None
+    if cfg.train_prior:
+        assert float(np.abs(G["grad/log_py"]).max()) > 1e-4 and float(res["reg_kl"]) != float(res["bpr"])
+    else:
+        assert G["grad/log_py"].size == 0 and P["log_py"].grad is None
 
 
 @pytest.mark.parametrize("name", ["divst_tiny", "divst_mid"])
@@ -48,7 +53,7 @@ def test_divst_forward_backward(name):
 def _train5(G, kind):
     cfg = golden_config(G)
     P = golden_params(G, requires_grad=True)
-    keys = O.trainable_keys(P)
+    keys = O.trainable_keys(P, bool(getattr(cfg, "train_prior", False)))
     m = {k: torch.zeros_like(P[k]) for k in keys}
     v = {k: torch.zeros_like(P[k]) for k in keys}
     losses = []
@@ -71,7 +76,8 @@ def _train5(G, kind):
     return cfg, P, np.array(losses), out
 
 
-@pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst"), ("divae_mid", "divae")])
+@pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst"), ("divae_mid", "divae"),
+                                       ("divae_tiny_prior", "divae"), ("divae_tiny_rowkl", "divae")])
 def test_adam_5_steps_and_greedy(name, kind):
     G = load_golden(name)
     cfg, P, losses, snaps = _train5(G, kind)
