@@ -268,6 +268,14 @@ int laed_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* s
 int laed_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
                    double lr, double beta1, double beta2, double eps, float grad_scale, void* stream);
 
+/* The other two optimizers get_optimizer can build (model_bases.py:126-133): torch.optim.SGD(lr, momentum) and
+ * torch.optim.RMSprop(lr, momentum) with torch's defaults (alpha 0.99, eps 1e-8, not centred); in place, state
+ * buffers start at zero; momentum_buf may be NULL when momentum == 0. */
+int laed_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, double lr, double momentum,
+                  float grad_scale, void* stream);
+int laed_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, double lr,
+                      double alpha, double eps, double momentum, float grad_scale, void* stream);
+
 /* small utilities */
 int laed_dot(const float* a, const float* b, int64_t n, float* out, void* stream);      /* out[0] = sum a*b (one block, fixed order) */
 int laed_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream);   /* y = a*x + b*y */

@@ -57,6 +57,32 @@ __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ y, c
         y[i] = sc * x[i];
 }
 
+// torch.optim.SGD (momentum, dampening 0, no nesterov / weight decay) and torch.optim.RMSprop (alpha, eps, momentum,
+// not centred) as model_bases.py:126-133 builds them; same op order as torch's single-tensor path.  buf starts at zero
+// (mu*0 + g equals torch's first-step clone of g).
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  int64_t n, float lr, float mu, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = g[i] * gs;
+        if (buf != nullptr) { d = buf[i] * mu + d; buf[i] = d; }
+        p[i] = p[i] - lr * d;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                      float* __restrict__ buf, int64_t n, float lr, float alpha, float oma,
+                                                      float eps, float mu, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gg = g[i] * gs;
+        const float s = sq[i] * alpha + (oma * gg) * gg;      /* mul_(alpha).addcmul_(g, g, value=1-alpha) */
+        sq[i] = s;
+        const float avg = sqrtf(s) + eps;
+        float d = gg / avg;
+        if (buf != nullptr) { d = buf[i] * mu + d; buf[i] = d; }
+        p[i] = p[i] - lr * d;
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t b = cdiv64(n, 256);
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -94,5 +120,28 @@ extern "C" int laed_scale_by_dev(float* y, const float* x, const float* s, int64
     LAED_CHECK_ARG(x && y && s, "scale_by_dev: null pointer");
     hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, s, n);
     LAED_LAUNCH_CHECK("scale_by_dev");
+    return 0;
+}
+
+extern "C" int laed_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, double lr, double momentum,
+                             float grad_scale, void* stream) {
+    LAED_CHECK_ARG(n >= 0, "sgd_step: bad size");
+    if (n == 0) return 0;
+    LAED_CHECK_ARG(p && g && (momentum == 0.0 || momentum_buf), "sgd_step: null pointer");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, momentum != 0.0 ? momentum_buf : nullptr,
+                       n, (float)lr, (float)momentum, grad_scale);
+    LAED_LAUNCH_CHECK("sgd_step");
+    return 0;
+}
+
+extern "C" int laed_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, double lr,
+                                 double alpha, double eps, double momentum, float grad_scale, void* stream) {
+    LAED_CHECK_ARG(n >= 0, "rmsprop_step: bad size");
+    if (n == 0) return 0;
+    LAED_CHECK_ARG(p && g && square_avg && (momentum <= 0.0 || momentum_buf), "rmsprop_step: null pointer");
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, square_avg,
+                       momentum > 0.0 ? momentum_buf : nullptr, n, (float)lr, (float)alpha, (float)(1.0 - alpha), (float)eps,
+                       (float)momentum, grad_scale);
+    LAED_LAUNCH_CHECK("rmsprop_step");
     return 0;
 }

@@ -42,10 +42,18 @@ class BaseModel(nn.Module):
         return self.valid_loss(loss, batch_cnt)
 
     def get_optimizer(self, config):
-        """model_bases.py:121-133.  Adam (the scripts' default, op='adam') = fused HIP kernel; under data
-        parallelism the optimizer first joins the overlapped gradient all-reduce."""
-        if config.op != 'adam':
-            raise NotImplementedError("optimizer '%s': only op='adam' (the default of every script) is built" % config.op)
-        params = [p for p in self.parameters() if p.requires_grad]
-        reducer = parallel.GradReducer(params) if parallel.group() is not None else None
-        return optim.FusedAdam(params, lr=config.init_lr, reducer=reducer)
+        """model_bases.py:121-133 on the fused HIP optimizers: Adam over the parameters that require grad (the
+        scripts' default, op='adam'), SGD / RMSprop over all parameters with config.momentum; under data parallelism
+        the optimizer first joins the overlapped gradient all-reduce."""
+        if config.op not in ('adam', 'sgd', 'rmsprop'):
+            return None                                             # the reference falls through and returns None
+        trainable = [p for p in self.parameters() if p.requires_grad]
+        reducer = parallel.GradReducer(trainable) if parallel.group() is not None else None
+        if config.op == 'adam':
+            print("Use adam")
+            return optim.FusedAdam(trainable, lr=config.init_lr, reducer=reducer)
+        if config.op == 'sgd':
+            print("Use SGD")
+            return optim.FusedSGD(self.parameters(), lr=config.init_lr, momentum=config.momentum, reducer=reducer)
+        print("RMSProp")
+        return optim.FusedRMSprop(self.parameters(), lr=config.init_lr, momentum=config.momentum, reducer=reducer)

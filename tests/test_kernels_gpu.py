@@ -239,6 +239,32 @@ def test_latent_losses(ops, O):
             assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5
 
 
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_sgd_and_rmsprop_vs_torch(ops, momentum):
+    """The sgd / rmsprop branches of get_optimizer (model_bases.py:126-133) against torch.optim on the CPU, 4 steps."""
+    from laed_amd import optim
+    for name in ("sgd", "rmsprop"):
+        shapes = [(37, 5), (1,), (1000,), (3, 4, 5)]
+        pc = [torch.nn.Parameter(rnd(*sh, seed=i)) for i, sh in enumerate(shapes)]
+        pg = [torch.nn.Parameter(dev(p.detach().clone())) for p in pc]
+        if name == "sgd":
+            oc, og = torch.optim.SGD(pc, lr=0.05, momentum=momentum), optim.FusedSGD(pg, lr=0.05, momentum=momentum)
+        else:
+            oc, og = torch.optim.RMSprop(pc, lr=0.01, momentum=momentum), optim.FusedRMSprop(pg, lr=0.01, momentum=momentum)
+        for step in range(4):
+            oc.zero_grad()
+            og.zero_grad()
+            for i, (a, b) in enumerate(zip(pc, pg)):
+                if i == 1 and step == 0:
+                    continue                                   # a parameter without a gradient is skipped, as torch does
+                g = rnd(*a.shape, seed=100 * step + i, scale=0.3)
+                a.grad, b.grad = g.clone(), dev(g)
+            oc.step()
+            og.step()
+            for a, b in zip(pc, pg):
+                assert float((b.detach().cpu() - a.detach()).abs().max()) < 2e-6 * max(1.0, float(a.abs().max())), (name, step)
+
+
 def test_attn_pool_and_tanh(ops):
     """RnnUttEncoder's attention pooling (encoders.py:119-130) and the prior network's tanh on their kernels, values
     and every gradient vs the same op sequence in torch CPU fp32; batch-first and time-major encoder memory."""
