@@ -33,6 +33,16 @@ static inline int laed_fail(int code, const char* fmt, ...) {
     do { hipError_t e_ = (expr); \
          if (e_ != hipSuccess) return laed_fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+// "done once per device" flag for hipFuncSetAttribute (function attributes are per device): true the first time it is
+// asked about the current device.  A benign race repeats the idempotent call at worst.
+static inline bool laed_first_use_on_device(uint64_t* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if ((*mask >> dev) & 1ull) return false;
+    *mask |= (1ull << dev);
+    return true;
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

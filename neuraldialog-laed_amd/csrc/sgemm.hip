@@ -449,12 +449,11 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
     constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
     auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT>;
-    static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
-    if (!attr_set) {
+    static uint64_t attr_set = 0;   // per device
+    if (laed_first_use_on_device(&attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return laed_fail((int)e, "sgemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
     }
     SgemmArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;

@@ -285,12 +285,11 @@ int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const
                          float* C, int64_t ldc, const float* bias, bool accumulate,
                          int splitk, int kper, float* ws, bool vec, float* rowsum_a, bool rowsum_acc, hipStream_t stream) {
     constexpr size_t lds = (size_t)2 * 2 * OPER * 16;
-    static bool attr_set[2] = {false, false};
+    static uint64_t attr_set[2] = {0, 0};   // per device
     const void* kern = vec ? reinterpret_cast<const void*>(xgemm_kernel<true>) : reinterpret_cast<const void*>(xgemm_kernel<false>);
-    if (!attr_set[vec ? 1 : 0]) {
+    if (laed_first_use_on_device(&attr_set[vec ? 1 : 0])) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return laed_fail((int)e, "xgemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[vec ? 1 : 0] = true;
     }
     XArgs p;
     p.A = A; p.B = B; p.C = C; p.bias = bias;
