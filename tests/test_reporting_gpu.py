@@ -160,3 +160,108 @@ def test_divst_generate():
     text = out.getvalue()
     assert text.count("Response: ") == 10 and text.count("Prev Predict: ") == 10 and text.count("Next Target: ") == 10
     assert "BLEU" in text and cfg.batch_size == 8
+
+
+def test_dialog_reporting_utilities():
+    """laed_amd.dialog_utils (= laed/dialog_utils.py) on a small AE-ED: the printed responses are the model's own GEN
+    output, the policy accuracy is recomputed from a direct pass, the latent dump holds the TEACH_FORCE latents."""
+    from laed_amd import dialog_utils
+    from laed_amd import main as engine
+    from laed_amd.dataset import data_loaders
+    from laed_amd.enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
+    from laed_amd.evaluators import BleuEvaluator
+    from laed_amd.models.dialog_models import AeED
+    from laed_amd.utils import Pack
+
+    class DCorpus(object):
+        vocab = ['<pad>', '<unk>', '<s>', '</s>', '<sys>', '<usr>'] + ['w%d' % i for i in range(6, V)]
+        rev_vocab = {w: i for i, w in enumerate(vocab)}
+
+    Td = 10
+    rs = np.random.RandomState(5)
+    dialogs = []
+    for _ in range(8):
+        turns = [Pack(utt=[2, 4, 6, 3], speaker=0, meta=None)]
+        start = int(rs.randint(6, V))
+        for t in range(int(rs.randint(4, 7))):
+            L = int(rs.randint(3, Td - 3))
+            body = [(start + t + j - 6) % (V - 6) + 6 for j in range(L)]
+            turns.append(Pack(utt=[2, 4 + t % 2] + body + [3], speaker=t % 2, meta=None))
+        dialogs.append(turns)
+    cfg = _cfg(max_utt_len=Td, max_dec_len=Td, utt_type='attn_rnn', utt_cell_size=8, ctx_cell_size=32, use_attribute=True,
+               greedy_q=True, freeze_step=1000, batch_size=4)
+    torch.manual_seed(2)
+    model = AeED(DCorpus(), cfg).cuda()
+    model.cat_connector.sample_uniform = lambda logits: torch.full(logits.shape, 0.5, device=logits.device)
+    feed = data_loaders.SMDDataLoader("Test", dialogs, cfg)
+    feed.epoch_init(cfg, shuffle=False, verbose=False)
+    n_batches, n_rows = feed.num_batch, feed.num_batch * cfg.batch_size
+
+    def first_batch():
+        feed.epoch_init(cfg, shuffle=False, verbose=False)
+        return feed.next_batch()
+
+    # generate: Source / Target / Predict per response, Predict = the model's greedy ids decoded
+    out = io.StringIO()
+    ev = BleuEvaluator("unit")
+    dialog_utils.generate(model, feed, cfg, ev, num_batch=None, dest_f=out)
+    text = out.getvalue()
+    assert text.count("Source: ") == n_rows and text.count("Predict: ") == n_rows and "BLEU" in text
+    assert len(ev.domain_hyps['default']) == n_rows and cfg.batch_size == 4
+    batch = first_batch()
+    model.eval()
+    with torch.no_grad():
+        outputs, labels = model(batch, mode=GEN, gen_type='greedy')
+    lines = text.split("\n")
+    assert lines[1] == "Target: " + _decode_d(DCorpus, labels[0].cpu().numpy())
+    assert lines[2] == "Predict: " + _decode_d(DCorpus, engine.sequences_of(outputs)[0])
+    assert lines[0] == "Source: <sys> w6"                         # the first response follows the opening turn only
+    assert any(l.startswith("Source: ") and "<t>" in l for l in lines)          # later ones carry several turns
+
+    # generate_with_adv: policy accuracy over the whole feed, recomputed from direct passes
+    hits = rows = 0
+    feed.epoch_init(cfg, shuffle=False, verbose=False)
+    while True:
+        b = feed.next_batch()
+        if b is None:
+            break
+        with torch.no_grad():
+            o, _ = model(b, mode=GEN, gen_type='greedy')
+        hits += int((torch.max(o[DecoderRNN.KEY_POLICY], dim=1)[1] == o[DecoderRNN.KEY_RECOG_LATENT].view(-1)).sum())
+        rows += o[DecoderRNN.KEY_POLICY].shape[0]
+    pi_acc = dialog_utils.generate_with_adv(model, feed, cfg, None, num_batch=None)
+    assert abs(pi_acc - hits / float(rows)) < 1e-12 and rows == n_rows * cfg.y_size
+
+    # dump_latent
+    buf = io.BytesIO()
+    dialog_utils.dump_latent(model, feed, cfg, buf, num_batch=None)
+    dump = pickle.loads(buf.getvalue())                          # a file this test wrote itself
+    assert len(dump['z']) == n_batches and len(dump['labels']) == n_rows and len(dump['contexts']) == n_rows
+    with torch.no_grad():
+        res = model(batch, mode=TEACH_FORCE, return_latent=True)
+    lq, lp, yi, di = dump['z'][0]
+    assert lq.shape == (4 * cfg.y_size, cfg.k) and lp.shape == lq.shape and di.shape == (4, 32)
+    assert np.array_equal(yi, res.y_ids.cpu().numpy()) and np.allclose(lp, res.log_py.cpu().numpy(), atol=1e-6)
+
+    # gen_with_cond: 5 policy samples per context, decoded greedily (Z) and by sampling words (W)
+    out = io.StringIO()
+    dialog_utils.gen_with_cond(model, feed, cfg, num_batch=2, dest_f=out)
+    text = out.getvalue()
+    assert text.count("Source: ") == 6 and text.count("Sample Z (") == 30 and text.count("Sample W (") == 30
+    assert cfg.batch_size == 4
+
+    # selective_generate: exactly the responses whose code is selected
+    codes = ['-'.join(map(str, r)) for r in outputs[DecoderRNN.KEY_LATENT].cpu().numpy().reshape(-1, cfg.y_size)]
+    data = dialog_utils.selective_generate(model, feed, cfg, [{'code': codes[0]}])
+    assert len(data) >= 1 and all(d['code'] == codes[0] for d in data)
+    assert data[0]['predict'] == _decode_d(DCorpus, engine.sequences_of(outputs)[codes.index(codes[0])])
+
+
+def _decode_d(corpus, ids):
+    words = []
+    for i in ids:
+        w = corpus.vocab[int(i)]
+        if w in ('</s>', '<pad>'):
+            break
+        words.append(w)
+    return " ".join(words)
