@@ -85,20 +85,28 @@ class GradReducer(object):
     def _flush(self):
         if not self._pending:
             return
-        grads, self._pending, self._pending_bytes = self._pending, [], 0
+        pending, self._pending, self._pending_bytes = self._pending, [], 0
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            # each gradient was finished on the stream its hook ran on (DI-VST's two decoders run, and are replayed by
+            # autograd, on two streams): wait for every producer, not only for the stream that triggered the flush
+            for _, ev in pending:
+                if ev is not None:
+                    self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                for g in grads:
+                for g, _ in pending:
                     g.record_stream(self.stream)
                     dist.all_reduce(g, group=_GROUP)
         else:                                   # CPU / gloo test path
-            for g in grads:
+            for g, _ in pending:
                 dist.all_reduce(g, group=_GROUP)
 
     def _hook(self, p):
         g = p.grad
-        self._pending.append(g)
+        ev = None
+        if self.stream is not None and g.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        self._pending.append((g, ev))
         self._pending_bytes += g.numel() * g.element_size()
         if self._pending_bytes >= self.bucket_bytes:
             self._flush()

@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, result_dir):
+def _worker(rank, world, port, result_dir, kind):
     import faulthandler
     # a rank that is still running after 100 s dumps every thread's stack and exits: the test then fails with the
     # place it was stuck at instead of hanging until the runner's own time limit
@@ -36,12 +36,12 @@ def _worker(rank, world, port, result_dir):
     from helpers import golden_config, load_golden, rel_err
     from laed_amd import parallel
     from laed_amd.enc2dec.decoders import TEACH_FORCE
-    from laed_amd.models.sent_models import DiVAE
+    from laed_amd.models.sent_models import DiVAE, DiVST
 
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     parallel.init()
-    G = load_golden("divae_mid")
+    G = load_golden(kind + "_mid")
     cfg = golden_config(G)
     cfg.use_gpu = True
 
@@ -49,7 +49,7 @@ def _worker(rank, world, port, result_dir):
         vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, int(G["config/vocab_size"]))]
         rev_vocab = {w: i for i, w in enumerate(vocab)}
 
-    model = DiVAE(Corpus(), cfg)
+    model = (DiVAE if kind == "divae" else DiVST)(Corpus(), cfg)
     model.load_state_dict({k: torch.from_numpy(np.array(G["sd/" + k])) for k in model.state_dict()})
     model.cuda().train()
     B = G["in/outputs"].shape[0]
@@ -60,14 +60,18 @@ def _worker(rank, world, port, result_dir):
     opt = model.get_optimizer(cfg)
     assert opt.reducer is not None and opt.reducer.enabled
     opt.zero_grad()
-    loss = model({"outputs": G["in/outputs"][b0:b1], "output_lens": [0] * (b1 - b0)}, mode=TEACH_FORCE)
+    feed = {"outputs": G["in/outputs"][b0:b1], "output_lens": [0] * (b1 - b0)}
+    if kind == "divst":                                    # two decoders on two HIP streams under the reducer's hooks
+        feed["prevs"], feed["nexts"] = G["in/prevs"][b0:b1], G["in/nexts"][b0:b1]
+    loss = model(feed, mode=TEACH_FORCE)
     model.backward(0, loss)
     opt.reducer.wait()
     torch.cuda.synchronize()
-    nll = loss.nll.detach().reshape(1).clone()
-    dist.all_reduce(nll)                                   # per-rank shares of the global 'word' NLL
-    assert abs(float(nll) - float(G["out/nll"])) < 1e-4 * abs(float(G["out/nll"]))
-    for k in ("reg_kl", "bpr"):                            # global-batch statistics: identical on every rank
+    for key in (("nll",) if kind == "divae" else ("prev_nll", "next_nll")):
+        nll = loss[key].detach().reshape(1).clone()
+        dist.all_reduce(nll)                               # per-rank shares of the global 'word' NLL
+        assert abs(float(nll) - float(G["out/" + key])) < 1e-4 * abs(float(G["out/" + key])), key
+    for k in (("reg_kl", "bpr") if kind == "divae" else ("reg_kl", "b_pr")):    # global-batch statistics: same on every rank
         assert abs(float(loss[k]) - float(G["out/" + k])) < 1e-7 + 1e-4 * abs(float(G["out/" + k])), k
     for n, p in model.named_parameters():
         g = G["grad/" + n]
@@ -82,10 +86,10 @@ def _worker(rank, world, port, result_dir):
     faulthandler.cancel_dump_traceback_later()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_dp_step_equals_reference_global_batch(tmp_path, world):
-    """divae_mid has 16 sequences: 8 or 4 per rank.  Loss terms, every gradient and the parameters after one Adam
+@pytest.mark.parametrize("world,kind", [(2, "divae"), (4, "divae"), (2, "divst")])
+def test_dp_step_equals_reference_global_batch(tmp_path, world, kind):
+    """The mid goldens have 12 sequences: 6 or 3 per rank.  Loss terms, every gradient and the parameters after one Adam
     step must equal the reference's single-process global-batch values whatever the rank count."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
     assert sorted(os.listdir(str(tmp_path))) == ["ok%d" % r for r in range(world)]
