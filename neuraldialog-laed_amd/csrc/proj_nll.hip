@@ -384,6 +384,16 @@ int launch_rows(float* L, int64_t rows, int V, int64_t ldl, const int64_t* label
 // dh = dl W has only (rows/128) x (H/128) output tiles but K = V is long: chunks that do not fill whole rounds of the
 // chip's 512 resident blocks (the last chunk, or every chunk of a small per-GPU batch) split K up to this many ways.
 constexpr int DH_SPLITS = 8;
+// dW = dl^T h has (V/128) x (H/128) output tiles: when that is under one round of the 512 block slots (the reference's
+// own vocabulary and hidden sizes) its K = rows may be split up to this many ways too
+constexpr int DW_SPLITS = 4;
+
+static int64_t split_ws_floats(int H, int V, int chunk_rows) {
+    int64_t n = (int64_t)DH_SPLITS * chunk_rows * H;
+    const int64_t t128 = (int64_t)((V + 127) / 128) * ((H + 127) / 128);
+    const int64_t dw = t128 < 512 ? (int64_t)DW_SPLITS * ((int64_t)V * H + V) : 0;
+    return n > dw ? n : dw;
+}
 
 extern "C" int laed_proj_nll_ldl(int V) { return (V + 31) / 32 * 32; }
 
@@ -391,7 +401,7 @@ extern "C" int laed_proj_nll_ldl(int V) { return (V + 31) / 32 * 32; }
 extern "C" int64_t laed_proj_nll_workspace(int H, int V, int chunk_rows) {
     const int64_t ldl = laed_proj_nll_ldl(V);
     int64_t n = (int64_t)chunk_rows * ldl;
-    n += (int64_t)DH_SPLITS * chunk_rows * H;          // split-K partials of the dh GEMM (short chunks, long K = V)
+    n += split_ws_floats(H, V, chunk_rows);            // split-K partials of the dh (long K = V) / small dW GEMMs
     if (laed_get_gemm_mode() == 1) {
         const int64_t ldr = (chunk_rows + 31) / 32 * 32;
         n += (int64_t)V * ldr + (int64_t)H * ldr + (int64_t)H * ldl;   // dl^T, h^T, W^T (K-contiguous operands)
@@ -423,7 +433,7 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
     const bool xmode = laed_get_gemm_mode() == 1 && with_grad;
     const int64_t ldr = (chunk_rows + 31) / 32 * 32;
     float* dh_ws = workspace + (int64_t)chunk_rows * ldl;          // [DH_SPLITS][chunk_rows][H] split-K partials
-    const int64_t dh_ws_floats = (int64_t)DH_SPLITS * chunk_rows * H;
+    const int64_t dh_ws_floats = split_ws_floats(H, V, chunk_rows);
     float* dlT = dh_ws + dh_ws_floats;                             // [V][ldr]
     float* hT = dlT + (int64_t)V * ldr;                    // [H][ldr]
     float* WT = hT + (int64_t)H * ldr;                     // [H][ldl]

@@ -489,41 +489,67 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     // sums over K of A (colsum) can only be served by that kernel and forces it.
     const bool force_x = !TA && TB && a.colsum != nullptr;
     const bool use_x = g_gemm_mode == 1 && !TA && TB && (force_x || t128 >= g_xgemm_min_tiles);
-    // Target >= 512 resident blocks (2 per CU).  Short-M/N problems with a long K get there by splitting K
-    // (needs caller workspace); the partial tiles are summed in a fixed order (reproducible).
-    bool big = use_x || t128 >= 192;
+    // Tile and split-K choice.  Problems of two rounds or more of the chip's 512 resident 128x128 blocks run as they
+    // are (128x128, no split).  Below that a small cost model, fitted to tools/gemm_sweep.py on the mid-size products
+    // of the reference's own batch sizes, prices every (tile, S):
+    //   time = R(n) * u * (K tiles per split + 4) + reduce(S),  n = blocks on the busiest of the 256 CUs,
+    //   a CU runs 2 blocks of 128x128 (u = 4.13 us per K tile) or 4 of 64x64 (u = 2.66 us per K tile of the four) at
+    //   once; a partly filled CU runs its blocks faster (R128(1) = 0.62, R64(1..3) = 0.27, 0.5, 0.75 of a full round);
+    //   a block pays ~4 K tiles of prologue/epilogue; S > 1 adds the fixed-order reduce ((S+1) M N floats at ~3 TB/s).
+    // Splitting needs caller workspace; the partial tiles are summed in a fixed order (reproducible).
+    bool big = true;
     int S = 1;
-    if (a.ws != nullptr && t128 < 512) {
+    if (!use_x && t128 < 1024) {
+        const int64_t per = (int64_t)a.M * a.N + (a.colsum ? a.M : 0);
+        const int64_t cap64 = a.ws != nullptr ? ws_floats / (per > 0 ? per : 1) : 1;
+        int smax = (int)(cap64 < 32 ? cap64 : 32);
+        if (smax > nkt / 4) smax = nkt / 4;               // keep >= 4 K tiles per split
+        if (smax < 1) smax = 1;
+        const float mn_mb = (float)per * 4.0e-6f;         // MB per partial product
+        float best = 1e30f;
+        for (int tile = 128; tile >= 64; tile -= 64) {
+            const int64_t tiles = tile == 128 ? t128 : t64;
+            for (int s = 1; s <= smax; ++s) {
+                const int64_t n = (tiles * s + 255) / 256;
+                float rounds;
+                if (tile == 128) rounds = (float)(n / 2) + ((n & 1) ? 0.62f : 0.f);
+                else { static const float part[4] = {0.f, 0.27f, 0.5f, 0.75f}; rounds = (float)(n / 4) + part[n & 3]; }
+                const int kt = (nkt + s - 1) / s;
+                float t = rounds * (tile == 128 ? 4.13f : 2.66f) * (float)(kt + 4);
+                if (s > 1) t += 4.0f + (float)(s + 1) * mn_mb / 3.0f;
+                if (t < best - 0.01f) { best = t; big = tile == 128; S = s; }
+            }
+        }
+    } else if (use_x && a.ws != nullptr && t128 < 512) {
+        // split-bf16 kernel (128x128 only): the split whose grid fills whole rounds of the 512 block slots
         const int64_t per = (int64_t)a.M * a.N + (a.colsum ? a.M : 0);
         const int64_t cap64 = ws_floats / (per > 0 ? per : 1);
-        const int cap = (int)(cap64 < 64 ? cap64 : 64);
-        const int by_k = nkt / 8;                         // keep >= 8 K tiles per split
-        if (use_x || (nkt >= 64 && t128 >= 128) || (nkt >= 512 && t128 >= 32)) {
-            // long-K problem on 128x128 tiles: pick the split whose grid fills whole rounds of the 512 resident
-            // block slots (2 per CU); e.g. 192 tiles: S=3 -> 576 blocks = 1.1 rounds (56 % busy), S=8 -> 3.0 rounds.
-            big = true;
-            int smax = by_k < cap ? by_k : cap;
-            if (smax > 32) smax = 32;
-            float best = -1.f;
-            for (int s = 1; s <= smax; ++s) {
-                const int64_t blocks = t128 * s;
-                const int64_t rounds = (blocks + 511) / 512;
-                const float eff = (float)blocks / (float)(rounds * 512) - 0.004f * (float)s;   // reduce cost grows with s
-                if (eff > best + 1e-6f) { best = eff; S = s; }
-            }
-        } else {
-            big = false;
-            const int want = (int)((512 + t64 - 1) / t64);
-            S = want < by_k ? want : by_k;
-            if (S > cap) S = cap;
-            if (S > 16) S = 16;
+        int smax = (int)(cap64 < 32 ? cap64 : 32);
+        if (smax > nkt / 8) smax = nkt / 8;
+        float best = -1.f;
+        for (int s = 1; s <= smax; ++s) {
+            const int64_t blocks = t128 * s;
+            const int64_t rounds = (blocks + 511) / 512;
+            const float eff = (float)blocks / (float)(rounds * 512) - 0.004f * (float)s;
+            if (eff > best + 1e-6f) { best = eff; S = s; }
         }
-        if (S < 1) S = 1;
-        if (S == 1) big = use_x || t128 >= 192;
     }
     if (force_split > 1 && a.ws != nullptr) {       // tail slab of a row-split problem: 128x128 tiles, K split as told
         big = true;
         S = force_split;
+    }
+    {   // experiment hook (tools/gemm_sweep.py): LAED_GEMM_FORCE="<tile>,<S>" overrides the choice above
+        static const char* fe = getenv("LAED_GEMM_FORCE");
+        if (fe != nullptr && !use_x) {
+            int ft = 0, fs = 0;
+            if (sscanf(fe, "%d,%d", &ft, &fs) == 2 && (ft == 64 || ft == 128) && fs >= 1) {
+                const int64_t per = (int64_t)a.M * a.N + (a.colsum ? a.M : 0);
+                if (fs > 1 && (a.ws == nullptr || ws_floats / (per > 0 ? per : 1) < fs)) fs = 1;
+                if (fs > nkt) fs = nkt;
+                big = ft == 128;
+                S = fs;
+            }
+        }
     }
     a.splitk = S;
     a.kper = ((nkt + S - 1) / S) * BK;

@@ -1,11 +1,16 @@
 """BaseModel: np2var, backward, valid_loss, model_sel_loss, get_optimizer (mirror of
 laed/models/model_bases.py:45-133; the Adam branch runs the fused HIP Adam kernel)."""
+import logging
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import optim, parallel
 from ..utils import cast_type
+
+
+logger = logging.getLogger()
 
 
 class BaseModel(nn.Module):
@@ -50,10 +55,10 @@ class BaseModel(nn.Module):
         trainable = [p for p in self.parameters() if p.requires_grad]
         reducer = parallel.GradReducer(trainable) if parallel.group() is not None else None
         if config.op == 'adam':
-            print("Use adam")
+            logger.info("Use adam")
             return optim.FusedAdam(trainable, lr=config.init_lr, reducer=reducer)
         if config.op == 'sgd':
-            print("Use SGD")
+            logger.info("Use SGD")
             return optim.FusedSGD(self.parameters(), lr=config.init_lr, momentum=config.momentum, reducer=reducer)
-        print("RMSProp")
+        logger.info("RMSProp")
         return optim.FusedRMSprop(self.parameters(), lr=config.init_lr, momentum=config.momentum, reducer=reducer)

@@ -39,8 +39,9 @@ def sgemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=Fals
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise _lib.LaedError("sgemm: operands must be fp32 CUDA tensors")
     ws, ws_n = None, 0
-    if splitk_ws and M * N <= (1 << 22) and K >= 2048:      # few output tiles, long K: let the library split K
-        ws_n = 8 * (M * N + M)
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if splitk_ws and t128 < 1024 and K >= 512:              # under two rounds of output tiles: the library may split K
+        ws_n = (8 if M * N <= (1 << 22) else 4) * (M * N + M)
         ws = workspace("sgemm_ws", ws_n, A.device)
     elif ws_floats > 0:                                     # caller-sized scratch (tail split of many-tile problems)
         ws_n = int(ws_floats)
