@@ -225,6 +225,16 @@ int laed_gru_decode_sample(const float* emb, const float* w_ih, const float* w_h
                            const float* u, uint64_t seed, uint64_t row0,
                            float* hbuf, float* xbuf, float* gates, float* logits, int64_t* ids_out, void* stream);
 
+/* One decode step at a time, for callers that drive their own loop (decoders.py:152-167 forward_step + :219 topk(1)):
+ *   laed_gru_cell_fwd: gates[B][3H] (scratch) = x W_ih^T + b_ih, then the fused recurrent step -> hout[B][H]
+ *                      (hout must not alias hprev);
+ *   laed_proj_argmax:  logits[B][ldl] (scratch, ldl = laed_proj_nll_ldl(V)) = h W_proj^T + b, ids[b] = first maximum
+ *                      (= topk(1) of the log-softmax). */
+int laed_gru_cell_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const float* hprev, int B, int E, int H, float* gates, float* hout, void* stream);
+int laed_proj_argmax(const float* h, const float* proj_w, const float* proj_b, int B, int H, int V,
+                     float* logits, int64_t* ids, void* stream);
+
 /* masked reductions used by NLLEntropy's averaging modes (criterions.py:47-68):
  * out[0] = sum_r tok_nll[r], out[1] = #(labels != pad). */
 int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int64_t N, int64_t pad_id, float* out, void* stream);

@@ -124,3 +124,25 @@ extern "C" int laed_gru_decode_sample(const float* emb, const float* w_ih, const
     return decode_loop(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, B, E, H, V, max_len, go_id, true, u, seed, row0,
                        hbuf, xbuf, gates, logits, ids_out, (hipStream_t)stream);
 }
+
+// ---- one decode step at a time (laed_gru_cell_fwd, laed_proj_argmax): the two halves of the loop above for
+// callers that drive their own loop (serving, beam-style search on the host)
+extern "C" int laed_gru_cell_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                 const float* hprev, int B, int E, int H, float* gates, float* hout, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAED_CHECK_ARG(B > 0 && E > 0 && H > 0, "gru_cell_fwd: bad size");
+    LAED_CHECK_ARG(x && w_ih && w_hh && b_ih && b_hh && hprev && gates && hout, "gru_cell_fwd: null pointer");
+    LAED_CHECK_ARG(hout != hprev, "gru_cell_fwd: hout must not alias hprev (blocks read other rows' h while writing theirs)");
+    LAED_TRY(laed_sgemm_impl(false, true, B, 3 * H, E, x, E, w_ih, E, gates, 3 * H, b_ih, false, nullptr, false, stream));
+    return laed_gru_step_impl(hprev, w_hh, b_hh, gates, hout, nullptr, B, H, stream);
+}
+
+extern "C" int laed_proj_argmax(const float* h, const float* proj_w, const float* proj_b, int B, int H, int V,
+                                float* logits, int64_t* ids, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LAED_CHECK_ARG(B > 0 && H > 0 && V > 0, "proj_argmax: bad size");
+    LAED_CHECK_ARG(h && proj_w && logits && ids, "proj_argmax: null pointer");
+    const int ldl = laed_proj_nll_ldl(V);
+    LAED_TRY(laed_sgemm_impl(false, true, B, V, H, h, H, proj_w, H, logits, ldl, proj_b, false, nullptr, false, stream));
+    return laed_argmax_rows(logits, B, V, ldl, ids, stream_);
+}

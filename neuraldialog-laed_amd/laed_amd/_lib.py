@@ -76,6 +76,8 @@ _SIGS = {
     "laed_get_gemm_mode": ([], _i),
     "laed_set_xgemm_min_tiles": ([_i], _i),
     "laed_dot": ([_p, _p, _i64, _p, _p], _i),
+    "laed_gru_cell_fwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p], _i),
+    "laed_proj_argmax": ([_p, _p, _p, _i, _i, _i, _p, _p, _p], _i),
     "laed_gru_decode_greedy": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p], _i),
     "laed_gru_decode_sample": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _p, _u64, _u64,
                                 _p, _p, _p, _p, _p, _p], _i),

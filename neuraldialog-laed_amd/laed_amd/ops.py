@@ -182,6 +182,27 @@ def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_i
     return ids[1:], hbuf
 
 
+def gru_cell(x, w_ih, w_hh, b_ih, b_hh, hprev):
+    """One GRU step (no tape): x [B,E], hprev [B,H] -> h [B,H]."""
+    B, E = x.shape
+    H = hprev.shape[1]
+    gates = torch.empty((B, 3 * H), device=x.device, dtype=torch.float32)
+    hout = torch.empty_like(hprev)
+    check(lib.laed_gru_cell_fwd(ptr(_f32c(x)), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(_f32c(hprev)), B, E, H,
+                                ptr(gates), ptr(hout), stream()), "laed_gru_cell_fwd")
+    return hout
+
+
+def proj_argmax(h, W, b):
+    """argmax_v (h W^T + b) per row, first maximum: h [B,H] -> ids [B] int64 (the greedy symbol of decoders.py:219)."""
+    B, H = h.shape
+    V = W.shape[0]
+    logits = torch.empty((B, proj_ldl(V)), device=h.device, dtype=torch.float32)
+    ids = torch.empty(B, device=h.device, dtype=I64)
+    check(lib.laed_proj_argmax(ptr(_f32c(h)), ptr(W), ptr(b), B, H, V, ptr(logits), ptr(ids, I64), stream()), "laed_proj_argmax")
+    return ids
+
+
 # ----------------------------------------------------------------------------------------------
 # autograd glue
 # ----------------------------------------------------------------------------------------------

@@ -567,6 +567,25 @@ def test_argmax_logsoftmax_greedy(ops, O):
     assert np.array_equal(ids_g.t().cpu().numpy(), seq_c.numpy())
 
 
+def test_single_step_entry_points_match_the_decode_loop(ops, O):
+    """laed_gru_cell_fwd + laed_proj_argmax driven from the host, one step at a time, reproduce laed_gru_decode_greedy's
+    ids (and so the oracle's greedy decode) exactly."""
+    for (B, E, H, V, L) in ((5, 12, 32, 57, 7), (70, 20, 48, 301, 5)):
+        emb, w_ih, w_hh = rnd(V, E, seed=1), rnd(3 * H, E, seed=2, scale=0.4), rnd(3 * H, H, seed=3, scale=0.4)
+        b_ih, b_hh = rnd(3 * H, seed=4, scale=0.1), rnd(3 * H, seed=5, scale=0.1)
+        pw, pb, h0 = rnd(V, H, seed=6), rnd(V, seed=7, scale=0.1), rnd(B, H, seed=8)
+        d = [dev(t) for t in (emb, w_ih, w_hh, b_ih, b_hh, pw, pb, h0)]
+        ids_loop, hbuf = ops.decode_greedy(*d, L, 2)
+        h, ids, steps = d[7], torch.full((B,), 2, device="cuda", dtype=torch.int64), []
+        for _ in range(L):
+            x = ops.EmbedFunction.apply(d[0], ids, None, 0.0, -1)
+            h = ops.gru_cell(x, d[1], d[2], d[3], d[4], h)
+            ids = ops.proj_argmax(h, d[5], d[6])
+            steps.append(ids)
+        assert np.array_equal(torch.stack(steps).cpu().numpy(), ids_loop.cpu().numpy())
+        assert torch.equal(h, hbuf[L])
+
+
 def test_single_use_tapes_refuse_a_second_backward():
     """GRU / fused projection rewrite their saved buffers in backward; a retained graph must not be run twice."""
     from laed_amd import ops
