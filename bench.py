@@ -43,7 +43,12 @@ SHAPES = {
     "P-fixed": (10002, 200, 512, 20, 10, 40, 30),         # ptb-utt.py defaults (configs[0] shape)
     "P-varlen": (10002, 200, 512, 20, 10, 40, 30),        # same, lengths ~ clip(round(lognormal(3.0, 0.45)), 3, 40)
     "VST-fixed": (10004, 200, 512, 20, 10, 40, 60),       # dailydialog-utt-skip.py defaults (configs[1] shape), DI-VST
+    # stanford-ae.py / stanford-skip.py defaults (configs[2], configs[3]): y=3, k=5, utt_cell 256, ctx/dec cell 512, B=30;
+    # every dialog context = DIALOG_CTX turns of T tokens (the loaders pad contexts to the batch maximum, <= backward_size)
+    "AE-fixed": (10004, 200, 512, 3, 5, 40, 30),
+    "ST-fixed": (10004, 200, 512, 3, 5, 40, 30),
 }
+DIALOG_CTX = 10
 
 
 TRAFFIC_NOTE = ("profiles/r1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
@@ -66,6 +71,15 @@ class Corpus(object):
     def __init__(self, V):
         self.vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
         self.rev_vocab = {w: i for i, w in enumerate(self.vocab)}
+
+
+def make_dialog_config(E, H, y, k, T, batch, skip):
+    """stanford-ae.py:33-91 / stanford-skip.py:33-93 defaults."""
+    return Namespace(embed_size=E, max_utt_len=T, num_layer=1, dropout=0.3, dec_cell_size=H, ctx_cell_size=H,
+                     utt_cell_size=256, bi_ctx_cell=False, rnn_cell='gru', max_dec_len=T, use_attn=False, beam_size=10,
+                     utt_type='rnn' if skip else 'attn_rnn', attn_type='cat', fix_batch=False, y_size=y, k=k, use_gpu=True,
+                     avg_type='word', use_reg_kl=True, use_attribute=True, greedy_q=True, init_lr=0.001, op='adam',
+                     momentum=0.0, batch_size=batch, freeze_step=5000 if skip else 4000, backward_size=10 if skip else 30)
 
 
 def make_config(E, H, y, k, T, batch, use_gpu=True):
@@ -151,6 +165,9 @@ def main():
     ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32 = exact fp32 MFMA everywhere (default); bf16x3 = opt-in split-bf16 x W^T products")
     ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform"], help="interior token id distribution")
+    ap.add_argument("--phase", default="B", choices=["A", "B"],
+                    help="AE-fixed / ST-fixed: A = recognition-network pretraining (before freeze_step), "
+                         "B = encoder-decoder training with the recognition network frozen (after it)")
     args = ap.parse_args()
     global IDS
     IDS = args.ids
@@ -170,6 +187,7 @@ def main():
     from laed_amd._lib import lib
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     from laed_amd.models.sent_models import DiVAE, DiVST
+    from laed_amd.models.dialog_models import AeED, StED
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -185,11 +203,20 @@ def main():
     same_job = args.workload == "S-fixed" and GB == SHAPES["S-fixed"][6] and world == 1 and args.ids == "zipf"   # what the PMC passes ran
 
     torch.manual_seed(0)                                     # identical replicas on every rank
-    cfg = make_config(E, H, y, k, T, GB)
     is_vst = args.workload == "VST-fixed"
-    model = (DiVST if is_vst else DiVAE)(Corpus(V), cfg).cuda()
+    is_dialog = args.workload in ("AE-fixed", "ST-fixed")
+    is_skip = args.workload == "ST-fixed"
+    if is_dialog:
+        if world != 1:
+            raise SystemExit("AE-fixed / ST-fixed are single-GPU workloads (the dialog models are not data-parallel)")
+        cfg = make_dialog_config(E, H, y, k, T, GB, is_skip)
+        model = (StED if is_skip else AeED)(Corpus(V), cfg).cuda()
+    else:
+        cfg = make_config(E, H, y, k, T, GB)
+        model = (DiVST if is_vst else DiVAE)(Corpus(V), cfg).cuda()
     model.train()
     opt = model.get_optimizer(cfg)
+    batch_cnt = 0
 
     def resident(a):                                         # this rank's rows, resident in HBM before timing
         return torch.from_numpy(a[rank * per:(rank + 1) * per].astype(np.int64)).cuda()
@@ -203,16 +230,30 @@ def main():
         tokens_per_step = GB * (T - 1) * (2 if is_vst else 1)
         enc_tokens_per_step = GB * T
     feed = {"outputs": resident(full), "output_lens": [T] * per}
-    if is_vst:
+    if is_vst or is_skip:
         feed["prevs"], feed["nexts"] = resident(synth_batch(V, T, GB, seed=1235)), resident(synth_batch(V, T, GB, seed=1236))
+    if is_dialog:
+        ctx = np.stack([synth_batch(V, T, GB, seed=2000 + c) for c in range(DIALOG_CTX)], axis=1)     # [B, C, T]
+        feed["contexts"], feed["context_lens"] = resident(ctx), [DIALOG_CTX] * per
+        enc_tokens_per_step = GB * T * (1 + DIALOG_CTX)
     step_flops = flops_per_step(V, E, H, y, k, T, GB, dec_positions=2 * (T - 1) if is_vst else None)
 
     def step():
         opt.zero_grad()
         loss = model(feed, mode=TEACH_FORCE)
-        model.backward(0, loss)
+        model.backward(batch_cnt, loss)
         opt.step()
         return loss
+
+    if is_dialog and args.phase == "B":
+        # flip to the encoder-decoder phase the way engine.train does (dialog_models.py:278-307, main.py:106-110): the
+        # first backward past freeze_step freezes the recognition side, then the optimizer is rebuilt
+        batch_cnt = cfg.freeze_step + 1
+        opt.zero_grad()
+        model.backward(batch_cnt, model(feed, mode=TEACH_FORCE))
+        assert model.flush_valid
+        model.flush_valid = False
+        opt = model.get_optimizer(cfg)
 
     def fence():
         torch.cuda.synchronize()
@@ -254,7 +295,10 @@ def main():
         if prof:
             lib.laed_prof_enable(0)
             lib.laed_prof_collect(prof_out)
-        nll = float((loss.prev_nll + loss.next_nll).detach()) if is_vst else float(loss.nll.detach())
+        if is_dialog and args.phase == "A":
+            nll = float((loss.vst_prev_nll + loss.vst_next_nll).detach()) if is_skip else float(loss.vae_nll.detach())
+        else:
+            nll = float((loss.prev_nll + loss.next_nll).detach()) if is_vst else float(loss.nll.detach())
         if dist.is_initialized():
             t = torch.tensor([elapsed, nll], device="cuda", dtype=torch.float64)
             tmax = t.clone()
@@ -267,7 +311,7 @@ def main():
         nfb = max(2, args.steps // 2)
         for _ in range(nfb):
             opt.zero_grad()
-            model.backward(0, model(feed, mode=TEACH_FORCE))
+            model.backward(batch_cnt, model(feed, mode=TEACH_FORCE))
             if opt.reducer is not None:
                 opt.reducer.wait()
         fence()
@@ -298,16 +342,18 @@ def main():
                                    "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3),
                                    "max": round(per_step[-1], 3)},
                 "encoder_tokens_per_s": round(enc_tokens_per_step * args.steps / elapsed, 1),
-                "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                "step_tflops": None if is_dialog else round(step_flops / (ms_per_step * 1e-3) / 1e12, 2),
                 "final_nll": round(nll, 5), "roofline": roofline}
 
     main_res = measure(args.gemm_mode)
-    alt_res = measure("bf16x3") if (args.gemm_mode == "fp32" and not args.no_alt) else None
+    alt_res = measure("bf16x3") if (args.gemm_mode == "fp32" and not args.no_alt and not is_dialog) else None
     _ops.set_gemm_mode("fp32")
 
     if rank == 0:
         out = {
-            "metric": "train tokens/sec (%s, whole node)" % ("DI-VST" if is_vst else "DI-VAE"),
+            "metric": "train tokens/sec (%s, whole node)" % (
+                "DI-VST" if is_vst else "DI-VAE" if not is_dialog else
+                ("ST-ED" if is_skip else "AE-ED") + (", encoder-decoder phase" if args.phase == "B" else ", pretraining phase")),
             "value": main_res["value"], "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "fwd_bwd_ms": main_res["fwd_bwd_ms"], "step_ms_device": main_res["step_ms_device"],
@@ -316,7 +362,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "ids": args.ids, "vocab": V, "embed": E, "hidden": H, "y_size": y, "k": k,
                        "seq_len": T, "global_batch": GB, "per_gpu_batch": per, "parallelism": "dp%d" % world,
-                       "tokens_per_step": tokens_per_step},
+                       "tokens_per_step": tokens_per_step,
+                       **({"context_turns": DIALOG_CTX, "phase": args.phase} if is_dialog else {})},
             "step_tflops": main_res["step_tflops"],
             "final_nll": main_res["final_nll"],
             "roofline": main_res["roofline"],

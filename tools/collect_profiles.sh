@@ -14,6 +14,9 @@ step timeout -k 10 200 python bench.py --ids uniform --no-alt --cpu-sample 0 > $
 for w in P-fixed P-varlen VST-fixed; do
   step timeout -k 10 200 python bench.py --workload $w --steps 50 --warmup 10 --no-alt > $O/bench_$w.json 2>> $O/bench.err
 done
+for w in AE-fixed ST-fixed; do for ph in A B; do
+  step timeout -k 10 200 python bench.py --workload $w --phase $ph --steps 50 --warmup 10 --cpu-sample 0 > $O/bench_${w}_$ph.json 2>> $O/bench.err
+done; done
 # 2. rocprofv3 kernel stats of the S-fixed step (same command line as the live-roofline line it is compared with)
 step timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_S-fixed -- python bench.py --steps 3 --warmup 1 --no-alt --cpu-sample 0 > $O/prof_S-fixed.json 2> $O/prof_S-fixed.err
 for w in P-fixed VST-fixed; do

@@ -15,7 +15,8 @@ def json_line(path):
     raise SystemExit("no JSON line in " + path)
 
 
-for name in ("S-fixed", "S-fixed_b512", "S-fixed_uniform", "P-fixed", "P-varlen", "VST-fixed"):
+for name in ("S-fixed", "S-fixed_b512", "S-fixed_uniform", "P-fixed", "P-varlen", "VST-fixed",
+             "AE-fixed_A", "AE-fixed_B", "ST-fixed_A", "ST-fixed_B"):
     d = json_line(os.path.join(SRC, "bench_%s.json" % name))
     json.dump(d, open(os.path.join(DST, "%s_bench_%s_1gpu.json" % (rnd, name)), "w"), indent=1)
     print("%-14s %10.1f tokens/s  %8.3f ms/step" % (name, d["value"], d["ms_per_step"]))
