@@ -1,4 +1,5 @@
-// GRU timestep kernels for SMALL batches (B <= 64: the reference's own script shapes, B = 30 / 60).
+// GRU timestep kernels for SMALL batches (B <= 64: the reference's own script shapes, B = 30 / 60) and, as row groups of
+// 64, for mid-size ones (the 300 utterances of an AE-ED / ST-ED batch).
 //
 // At these sizes a timestep is ~50 MFLOP against 3-12 MB of recurrent weights: what matters is how many CUs pull
 // W_hh out of L2 at once and how short the dependent chain inside the kernel is, not MFMA throughput.  The tiled
@@ -117,14 +118,17 @@ __global__ __launch_bounds__(NTH) void gru_small_fwd_kernel(SmallFwdArgs p) {
     __shared__ float red[NW * BP * NC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, B = p.B, j0 = blockIdx.x * UF;
+    // batches of more than 64 rows run as row groups of BP rows (blockIdx.y), each with its own quad-major operand
+    const int64_t xg = (int64_t)blockIdx.y * H * BP;
     // epilogue operands of this thread's (row, unit) pair: fetched now, needed after the reduction
     const int row = tid / UF, u = tid % UF, j = j0 + u;
-    const bool mine = row < B;
+    const int grow = blockIdx.y * BP + row;
+    const bool mine = row < BP && grow < B;
     float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f;
-    float* g = p.gates + (int64_t)row * 3 * H;
+    float* g = p.gates + (int64_t)grow * 3 * H;
     if (mine) {
         gi_r = g[j]; gi_z = g[H + j]; gi_n = g[2 * H + j];
-        hp = p.hprev[(int64_t)row * H + j];
+        hp = p.hprev[(int64_t)grow * H + j];
         bhr = p.b_hh[j]; bhz = p.b_hh[H + j]; bhn = p.b_hh[2 * H + j];
     }
     if (wave < p.nkw) {
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(NTH) void gru_small_fwd_kernel(SmallFwdArgs p) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
-        small_core<RT, NC>(p.hx_in, p.wp + (int64_t)blockIdx.x * H * NC, H / 16 / p.nkw, wave, lane, acc);
+        small_core<RT, NC>(p.hx_in + xg, p.wp + (int64_t)blockIdx.x * H * NC, H / 16 / p.nkw, wave, lane, acc);
         spill_partials<RT, NC>(red, acc, wave, lane);
     }
     __syncthreads();
@@ -146,13 +150,13 @@ __global__ __launch_bounds__(NTH) void gru_small_fwd_kernel(SmallFwdArgs p) {
         const float z = sigmoidf_acc(gi_z + ghz + bhz);
         const float n = tanhf(gi_n + r * ghn);
         h = (1.0f - z) * n + z * hp;
-        p.hout[(int64_t)row * H + j] = h;
+        p.hout[(int64_t)grow * H + j] = h;
         if (p.hn != nullptr) {
             g[j] = r; g[H + j] = z; g[2 * H + j] = n;
-            p.hn[(int64_t)row * H + j] = ghn;
+            p.hn[(int64_t)grow * H + j] = ghn;
         }
     }
-    p.hx_out[((int64_t)(j / 4) * BP + row) * 4 + (j & 3)] = h;      // padding rows carry zeros
+    p.hx_out[xg + ((int64_t)(j / 4) * BP + row) * 4 + (j & 3)] = h;      // padding rows carry zeros
 }
 
 struct SmallBwdArgs {
@@ -174,11 +178,13 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
     __shared__ float red[NW * BP * NC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, B = p.B, j0 = blockIdx.x * UB, K = 3 * H;
+    const int64_t xg = (int64_t)blockIdx.y * K * BP;          // row group (see the forward kernel)
     const int row = tid / UB, u = tid % UB, j = j0 + u;
-    const bool mine = row < B;
-    const int64_t i = (int64_t)row * H + j;
+    const int grow = blockIdx.y * BP + row;
+    const bool mine = row < BP && grow < B;
+    const int64_t i = (int64_t)grow * H + j;
     float dh = 0.f, r = 0.f, z = 0.f, nn = 0.f, hnv = 0.f, hp = 0.f;
-    float* g = p.gates + (int64_t)row * 3 * H;
+    float* g = p.gates + (int64_t)grow * 3 * H;
     if (mine) {
         dh = p.dh[i];
         if (!p.final_step) {
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
-            small_core<RT, NC>(p.dx_in, p.wpT + (int64_t)blockIdx.x * K * NC, K / 16 / p.nkw, wave, lane, acc);
+            small_core<RT, NC>(p.dx_in + xg, p.wpT + (int64_t)blockIdx.x * K * NC, K / 16 / p.nkw, wave, lane, acc);
             spill_partials<RT, NC>(red, acc, wave, lane);
         }
         __syncthreads();
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
     if (p.final_step) { if (mine) p.dh[i] = dh; return; }
     float drp = 0.f, dzp = 0.f, dnr = 0.f;
     if (mine) {
-        float* d = p.dgh + (int64_t)row * 3 * H;
+        float* d = p.dgh + (int64_t)grow * 3 * H;
         const float dn = dh * (1.0f - z);
         const float dz = dh * (hp - nn);
         const float dnp = dn * (1.0f - nn * nn);
@@ -216,9 +222,9 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
         p.dh[i] = dh * z;
     }
     const int e4 = j & 3;
-    p.dx_out[((int64_t)(j / 4) * BP + row) * 4 + e4] = drp;           // padding rows carry zeros
-    p.dx_out[((int64_t)((H + j) / 4) * BP + row) * 4 + e4] = dzp;
-    p.dx_out[((int64_t)((2 * H + j) / 4) * BP + row) * 4 + e4] = dnr;
+    p.dx_out[xg + ((int64_t)(j / 4) * BP + row) * 4 + e4] = drp;           // padding rows carry zeros
+    p.dx_out[xg + ((int64_t)((H + j) / 4) * BP + row) * 4 + e4] = dzp;
+    p.dx_out[xg + ((int64_t)((2 * H + j) / 4) * BP + row) * 4 + e4] = dnr;
 }
 
 // ---- persistent forward: ALL T steps in one launch, the workgroup's W_hh slab resident in LDS across timesteps.
@@ -501,12 +507,15 @@ __global__ __launch_bounds__(256) void pack_w_bwd_kernel(const float* __restrict
     }
 }
 
-// xq[q][row][e] = row < B ? m[row][4q + e] : 0      (K = row length of m, BP padded rows)
-__global__ __launch_bounds__(256) void rows_to_quads_kernel(const float* __restrict__ m, int B, int K, int BP, float* __restrict__ xq) {
-    const int64_t n = (int64_t)(K / 4) * BP;
+// xq[grp][q][row][e] = grp BP + row < B ? m[grp BP + row][4q + e] : 0      (K = row length of m, groups of BP padded rows)
+__global__ __launch_bounds__(256) void rows_to_quads_kernel(const float* __restrict__ m, int B, int K, int BP, int groups,
+                                                            float* __restrict__ xq) {
+    const int64_t per = (int64_t)(K / 4) * BP, n = per * groups;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i % BP);
-        const int q = (int)(i / BP);
+        const int grp = (int)(i / per);
+        const int64_t r = i - (int64_t)grp * per;
+        const int row = grp * BP + (int)(r % BP);
+        const int q = (int)(r / BP);
         float* d = xq + i * 4;
         if (row < B) {
             const float* s = m + (int64_t)row * K + 4 * q;
@@ -540,31 +549,46 @@ void launch_rt(int B, dim3 grid, hipStream_t stream, const A& a, K1 k1, K2 k2, K
 
 }   // namespace
 
-// B <= 64 rows, H a multiple of 16 (quads, whole MFMA k-groups, whole unit slices)
+// Row groups: up to 64 rows one group (padded to whole 16-row MFMA tiles); larger batches run as groups of 64 rows in
+// blockIdx.y of the per-step kernels, each group re-reading the packed W_hh out of L2.
+static int small_groups(int B) { return B <= 64 ? 1 : (B + 63) / 64; }
+
+// H a multiple of 16 (quads, whole MFMA k-groups, whole unit slices) and
+//   B <= 64: the reference's own batch sizes (persistent launches), or
+//   64 < B <= 512 while the groups' W_hh reads stay under 32 MB per step (AE-ED / ST-ED utterance encoders: B x turns
+//   = 300 sequences of H = 256): per-step launches of the packed core, ~2x faster there than the tiled step kernel,
+//   which needs >= 256 of its 64-row x 32-unit tiles to fill the chip.  LAED_GRU_MID=0 keeps the tiled kernels.
 bool laed_gru_small_ok(int B, int H) {
-    return small_enabled() && getenv("LAED_GRU_WM") == nullptr && B >= 1 && B <= 64 && H >= 16 && (H % 16) == 0;
+    if (!(small_enabled() && getenv("LAED_GRU_WM") == nullptr && B >= 1 && H >= 16 && (H % 16) == 0)) return false;
+    if (B <= 64) return true;
+    static const bool mid = []() { const char* e = getenv("LAED_GRU_MID"); return !(e != nullptr && atoi(e) == 0); }();
+    return mid && B <= 512 && (int64_t)small_groups(B) * 3 * H * H * 4 <= ((int64_t)32 << 20);
 }
 
-int laed_gru_small_bp(int B) { return (B + 15) / 16 * 16; }
+int laed_gru_small_bp(int B) { return B <= 64 ? (B + 15) / 16 * 16 : 64; }
 
-int64_t laed_gru_small_fwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * H * laed_gru_small_bp(B) + 64; }
-int64_t laed_gru_small_bwd_ws(int B, int H) { return (int64_t)3 * H * H + (int64_t)2 * 3 * H * laed_gru_small_bp(B) + 64; }
+int64_t laed_gru_small_fwd_ws(int B, int H) {
+    return (int64_t)3 * H * H + (int64_t)2 * H * laed_gru_small_bp(B) * small_groups(B) + 64;
+}
+int64_t laed_gru_small_bwd_ws(int B, int H) {
+    return (int64_t)3 * H * H + (int64_t)2 * 3 * H * laed_gru_small_bp(B) * small_groups(B) + 64;
+}
 
 // forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
 int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
                        float* ws, hipStream_t stream) {
-    const int BP = laed_gru_small_bp(B);
+    const int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wp = ws;
-    float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP};
+    float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP * NG};
     hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wp);
     LAED_LAUNCH_CHECK("gru_small pack_w_fwd");
-    hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, hx[0]);
+    hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32 * NG), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, NG, hx[0]);
     LAED_LAUNCH_CHECK("gru_small rows_to_quads");
     // default: one persistent launch with LDS-resident W_hh (4.9 vs 6.3 us per step + launch gaps at B = 30, H = 512);
     // LAED_GRU_PERSIST=0 selects the per-step launches below
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
-    if (persist && H / UF <= 256) {
+    if (persist && NG == 1 && H / UF <= 256) {
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP);
         hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
         if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
@@ -595,7 +619,7 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
         a.gates = gates + (int64_t)t * B * 3 * H; a.hout = hbuf + (int64_t)(t + 1) * BH;
         a.hn = hn ? hn + (int64_t)t * BH : nullptr; a.hx_out = hx[(t + 1) & 1];
         a.B = B; a.H = H; a.nkw = k_waves(H);
-        launch_rt(B, dim3(H / UF), stream, a, gru_small_fwd_kernel<1>, gru_small_fwd_kernel<2>, gru_small_fwd_kernel<3>,
+        launch_rt(B, dim3(H / UF, NG), stream, a, gru_small_fwd_kernel<1>, gru_small_fwd_kernel<2>, gru_small_fwd_kernel<3>,
                   gru_small_fwd_kernel<4>);
         LAED_LAUNCH_CHECK("gru_small_fwd");
     }
@@ -606,14 +630,14 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
 // ws: laed_gru_small_bwd_ws floats, 16-byte aligned.
 int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, float* gates, float* dgh,
                        float* dh0, int T, int B, int H, float* ws, hipStream_t stream) {
-    const int BP = laed_gru_small_bp(B);
+    const int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wpT = ws;
-    float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP};
+    float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP * NG};
     hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT);
     LAED_LAUNCH_CHECK("gru_small pack_w_bwd");
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
-    if (persist && H / UB <= 256) {
+    if (persist && NG == 1 && H / UB <= 256) {
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * BP);
         hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
         if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
@@ -651,7 +675,7 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
         a.dgh = fin ? nullptr : dgh + (int64_t)t * B * 3 * H;
         a.dx_out = fin ? nullptr : dx[t & 1];
         a.dh = dh0; a.B = B; a.H = H; a.nkw = k_waves(3 * H); a.final_step = fin ? 1 : 0;
-        launch_rt(B, dim3(H / UB), stream, a, gru_small_bwd_kernel<1>, gru_small_bwd_kernel<2>, gru_small_bwd_kernel<3>,
+        launch_rt(B, dim3(H / UB, NG), stream, a, gru_small_bwd_kernel<1>, gru_small_bwd_kernel<2>, gru_small_bwd_kernel<3>,
                   gru_small_bwd_kernel<4>);
         LAED_LAUNCH_CHECK("gru_small_bwd");
     }

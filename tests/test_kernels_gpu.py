@@ -190,6 +190,14 @@ def test_gru_small_batch_kernels(ops, O, T, B, E, H, with_h0):
     _gru_case(ops, O, T, B, E, H, with_h0, seed=30, tol=1e-5)
 
 
+@pytest.mark.parametrize("T,B,E,H,with_h0", [(4, 65, 12, 32, True), (6, 300, 40, 256, False), (3, 128, 16, 64, True),
+                                             (2, 511, 8, 48, True), (5, 129, 20, 512, False)])
+def test_gru_mid_batch_row_groups(ops, O, T, B, E, H, with_h0):
+    """64 < B <= 512 (the B x turns utterances of an AE-ED / ST-ED batch): the packed per-step kernels over row groups
+    of 64, ragged last group included."""
+    _gru_case(ops, O, T, B, E, H, with_h0, seed=40, tol=1e-5)
+
+
 def test_gru_all_tile_configs(ops, O):
     # the block-tile choice is a pure launch-geometry decision: every forced config must agree
     try:
