@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const
 
 __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ s, int64_t n) {
     const float sc = s[0];
+    if (sc == 1.0f && x == y) return;      // in place by exactly 1 (the usual d loss of a train step): nothing to move
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = sc * x[i];
 }
