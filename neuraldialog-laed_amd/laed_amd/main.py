@@ -16,6 +16,7 @@ import torch
 
 from .dataset.corpora import EOS, EOT, PAD
 from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
+from .models.model_bases import summary
 from .utils import get_dekenize
 
 logger = logging.getLogger()
@@ -100,6 +101,7 @@ def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=
     done_epoch = 0
     train_loss = LossManager()
     model.train()
+    logger.info(summary(model, show_weights=False))
     logger.info("**** Training Begins ****")
     logger.info("**** Epoch 0/{} ****".format(config.max_epoch))
     while True:

@@ -13,6 +13,25 @@ from ..utils import cast_type
 logger = logging.getLogger()
 
 
+def summary(model, show_weights=True, show_parameters=True):
+    """One line per child module with its weight shapes and parameter count, then the total -- the model description
+    the training loop logs before it starts (model_bases.py:12-42, main.py:93)."""
+    lines, total = [model.__class__.__name__ + ' ('], 0
+    for key, module in model._modules.items():
+        text = summary(module) if isinstance(module, nn.Sequential) else repr(module)
+        text = text.replace('\n', '\n  ')
+        shapes = tuple(tuple(p.size()) for p in module.parameters())
+        count = int(sum(p.numel() for p in module.parameters()))
+        total += count
+        line = '  (' + key + '): ' + text
+        if show_weights:
+            line += ', weights={}'.format(shapes)
+        if show_parameters:
+            line += ', parameters={}'.format(count)
+        lines.append(line)
+    return '\n'.join(lines) + '\n) Total Parameters={}'.format(total)
+
+
 class BaseModel(nn.Module):
     def __init__(self, config):
         super(BaseModel, self).__init__()

@@ -27,6 +27,20 @@ def test_state_dict_keys_match_reference_checkpoints():
         model.load_state_dict({k: torch.from_numpy(np.array(G["sd/" + k])) for k in model.state_dict()})
 
 
+def test_summary_counts_parameters_like_the_reference():
+    """model_bases.summary: per-child parameter counts; modules that share a table (the decoder's embedding) are counted
+    under every child that holds them, as the reference's does."""
+    from laed_amd.models.model_bases import summary
+    from laed_amd.models.sent_models import DiVAE
+    G = load_golden("divae_tiny")
+    model = DiVAE(Corpus(int(G["config/vocab_size"])), golden_config(G))
+    text = summary(model, show_weights=False)
+    per_child = sum(sum(p.numel() for p in m.parameters()) for m in model._modules.values())
+    assert text.startswith("DiVAE (") and text.endswith("Total Parameters={}".format(per_child))
+    assert "(x_encoder):" in text and "(decoder):" in text and "weights=" not in text
+    assert "weights=" in summary(model)
+
+
 def test_same_seed_same_init_as_torch_modules():
     """GRU / Linear / Embedding keep torch's initialisation order: same manual_seed -> same weights as nn.GRU etc."""
     from laed_amd.enc2dec.base_modules import GRU
