@@ -3,10 +3,16 @@
 Reference: laed/utils.py:17-55,119-157.  The tokenisers are the reference's regular expressions (`nltk.RegexpTokenizer`
 = `re.findall` with UNICODE | MULTILINE | DOTALL); the detokeniser stands in for nltk's MosesDetokenizer (absent here:
 PARITY UNPINNED), with the English punctuation / contraction rules that matter for the corpora's lower-cased text.
-Session-dir helpers are out of scope.
+The session helpers at the end (run directory, session.log, params.json, forward_only reload) follow utils.py:58-117.
 """
+import json
+import logging
+import os
 import re
+import sys
+from argparse import Namespace
 from collections import defaultdict
+from datetime import datetime
 
 import torch
 
@@ -80,3 +86,50 @@ class missingdict(defaultdict):
 
     def __missing__(self, key):
         return self.default_factory()
+
+
+# ---- session plumbing of the driver scripts (utils.py:58-117): a run's directory, its log file and params.json ----
+def get_time():
+    return datetime.now().strftime("%Y-%m-%dT%H-%M-%S")
+
+
+def load_config(load_path):
+    """params.json of a session -> Namespace (utils.py:108-112)."""
+    with open(load_path, "r") as fp:
+        return Namespace(**json.load(fp))
+
+
+def process_config(config):
+    """forward_only runs take every setting from the loaded session's params.json except the decoding-time ones
+    (utils.py:58-73)."""
+    if getattr(config, "forward_only", False):
+        keep = {k: getattr(config, k) for k in ("load_sess", "backward_size", "beam_size", "gen_type") if hasattr(config, k)}
+        config = load_config(os.path.join(config.log_dir, config.load_sess, "params.json"))
+        config.forward_only = True
+        for k, v in keep.items():
+            setattr(config, k, v)
+        config.batch_size = 50
+    return config
+
+
+def prepare_dirs_loggers(config, script=""):
+    """Root logger to stdout; for training runs also <log_dir>/<time>[-script]/session.log, with the configuration saved
+    next to it as params.json (utils.py:76-105)."""
+    fmt = logging.Formatter("%(message)s")
+    root = logging.getLogger()
+    root.setLevel(logging.DEBUG)
+    console = logging.StreamHandler(sys.stdout)
+    console.setLevel(logging.DEBUG)
+    console.setFormatter(fmt)
+    root.addHandler(console)
+    if getattr(config, "forward_only", False):
+        return
+    os.makedirs(config.log_dir, exist_ok=True)
+    config.session_dir = os.path.join(config.log_dir, "{}-{}".format(get_time(), script) if script else get_time())
+    os.mkdir(config.session_dir)
+    log_file = logging.FileHandler(os.path.join(config.session_dir, "session.log"))
+    log_file.setLevel(logging.DEBUG)
+    log_file.setFormatter(fmt)
+    root.addHandler(log_file)
+    with open(os.path.join(config.session_dir, "params.json"), "w") as fp:
+        json.dump(vars(config), fp, indent=4, sort_keys=True)

@@ -41,6 +41,41 @@ def test_summary_counts_parameters_like_the_reference():
     assert "weights=" in summary(model)
 
 
+def test_session_dirs_and_forward_only_reload(tmp_path):
+    """prepare_dirs_loggers / process_config / load_config (utils.py:58-117): a training run gets a time-stamped session
+    directory with session.log and params.json; a forward_only run reloads them and keeps its decoding-time flags."""
+    import json
+    import logging
+    import os
+    from argparse import Namespace
+    from laed_amd.utils import load_config, prepare_dirs_loggers, process_config
+    root = logging.getLogger()
+    before = list(root.handlers)
+    try:
+        cfg = Namespace(log_dir=str(tmp_path / "logs"), forward_only=False, y_size=20, k=10, gen_type="greedy", beam_size=10,
+                        backward_size=5, batch_size=30, load_sess="")
+        prepare_dirs_loggers(cfg, "ptb-utt.py")
+        assert os.path.isdir(cfg.session_dir) and cfg.session_dir.endswith("-ptb-utt.py")
+        logging.getLogger().info("hello session")
+        for h in root.handlers:
+            h.flush()
+        assert "hello session" in open(os.path.join(cfg.session_dir, "session.log")).read()
+        saved = json.load(open(os.path.join(cfg.session_dir, "params.json")))
+        assert saved["y_size"] == 20 and saved["session_dir"] == cfg.session_dir
+        again = Namespace(log_dir=cfg.log_dir, forward_only=True, load_sess=os.path.basename(cfg.session_dir),
+                          backward_size=9, beam_size=3, gen_type="sample", batch_size=7, y_size=-1)
+        out = process_config(again)
+        assert (out.y_size, out.k, out.backward_size, out.beam_size, out.gen_type, out.batch_size) == (20, 10, 9, 3, "sample", 50)
+        assert out.forward_only and out.load_sess == again.load_sess
+        assert vars(load_config(os.path.join(cfg.session_dir, "params.json")))["k"] == 10
+        assert process_config(cfg) is cfg
+    finally:
+        for h in list(root.handlers):
+            if h not in before:
+                root.removeHandler(h)
+                h.close()
+
+
 def test_same_seed_same_init_as_torch_modules():
     """GRU / Linear / Embedding keep torch's initialisation order: same manual_seed -> same weights as nn.GRU etc."""
     from laed_amd.enc2dec.base_modules import GRU
