@@ -136,6 +136,51 @@ def test_adam_steps_eval_and_greedy_vs_reference(name, kind):
 
 
 @pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst")])
+def test_loss_curve_60_steps_vs_oracle(name, kind):
+    """Sixty train steps (fresh Gumbel noise each step, main.py:104-113 order) on the GPU against the oracle stepping the
+    same weights on the CPU: every step's loss terms stay within the north-star tolerance -- no drift builds up."""
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from helpers import golden_params
+    from oracle import laed_oracle as O
+    G = load_golden(name)
+    model, cfg = build(G, kind)
+    model.train()
+    opt = model.get_optimizer(cfg)
+    feed = feed_of(G, kind)
+    P = golden_params(G, requires_grad=True)
+    keys = O.trainable_keys(P)
+    m = {k: torch.zeros_like(P[k]) for k in keys}
+    v = {k: torch.zeros_like(P[k]) for k in keys}
+    rs = np.random.RandomState(5)
+    R, kk = int(cfg.y_size) * G["in/outputs"].shape[0], int(cfg.k)
+    names = ("nll", "reg_kl") if kind == "divae" else ("prev_nll", "next_nll", "reg_kl")
+    worst = 0.0
+    for step in range(60):
+        u = rs.uniform(size=(R, kk)).astype(np.float32)
+        for k in keys:
+            P[k].grad = None
+        if kind == "divae":
+            ref = O.divae_forward(P, cfg, G["in/outputs"], u)
+        else:
+            ref = O.divst_forward(P, cfg, G["in/outputs"], G["in/prevs"], G["in/nexts"], u)
+        ref["total"].backward()
+        with torch.no_grad():
+            for k in keys:
+                O.adam_step(P[k], P[k].grad, m[k], v[k], step + 1, lr=float(cfg.init_lr))
+        inject_u(model, u)
+        opt.zero_grad()
+        loss = model(feed, mode=TEACH_FORCE)
+        model.backward(step, loss)
+        opt.step()
+        for n in names:
+            a, b = float(loss[n]), float(ref[n])
+            worst = max(worst, abs(a - b) / (abs(b) + 1e-6))
+            assert abs(a - b) <= 2e-6 + LOSS_RTOL * abs(b), (step, n, a, b)
+    assert float(loss[names[0]]) < float(G["out/" + names[0]])         # and it trains
+    print("worst relative loss deviation over 60 steps: %.2e" % worst)
+
+
+@pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst")])
 def test_dropout_mask_injection_vs_reference(name, kind):
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     G = load_golden(name)
