@@ -154,7 +154,7 @@ def test_loss_curve_60_steps_vs_oracle(name, kind):
     rs = np.random.RandomState(5)
     R, kk = int(cfg.y_size) * G["in/outputs"].shape[0], int(cfg.k)
     names = ("nll", "reg_kl") if kind == "divae" else ("prev_nll", "next_nll", "reg_kl")
-    worst = 0.0
+    worst = {n: 0.0 for n in names}          # reg_kl is ~5e-3: its relative figure is fp32 round-off over a tiny value
     for step in range(60):
         u = rs.uniform(size=(R, kk)).astype(np.float32)
         for k in keys:
@@ -174,10 +174,10 @@ def test_loss_curve_60_steps_vs_oracle(name, kind):
         opt.step()
         for n in names:
             a, b = float(loss[n]), float(ref[n])
-            worst = max(worst, abs(a - b) / (abs(b) + 1e-6))
+            worst[n] = max(worst[n], abs(a - b) / (abs(b) + 1e-6))
             assert abs(a - b) <= 2e-6 + LOSS_RTOL * abs(b), (step, n, a, b)
     assert float(loss[names[0]]) < float(G["out/" + names[0]])         # and it trains
-    print("worst relative loss deviation over 60 steps: %.2e" % worst)
+    print("worst relative deviation over 60 steps:", {n: "%.1e" % w for n, w in worst.items()})
 
 
 @pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst")])
