@@ -154,7 +154,10 @@ def test_loss_curve_60_steps_vs_oracle(name, kind):
     rs = np.random.RandomState(5)
     R, kk = int(cfg.y_size) * G["in/outputs"].shape[0], int(cfg.k)
     names = ("nll", "reg_kl") if kind == "divae" else ("prev_nll", "next_nll", "reg_kl")
-    worst = {n: 0.0 for n in names}          # reg_kl is ~5e-3: its relative figure is fp32 round-off over a tiny value
+    # reg_kl is quadratically small near the uniform prior (~ sum (qbar - 1/k)^2 k/2 ~ 5e-3): an absolute drift of 1e-6 in
+    # qbar -- sixty fp32 Adam steps in two summation orders -- is a few 1e-4 of it, which is why the check below carries
+    # an absolute term; on identical weights (step 0) the terms agree to ~1e-6 relative
+    worst, first = {n: 0.0 for n in names}, {}
     for step in range(60):
         u = rs.uniform(size=(R, kk)).astype(np.float32)
         for k in keys:
@@ -175,9 +178,13 @@ def test_loss_curve_60_steps_vs_oracle(name, kind):
         for n in names:
             a, b = float(loss[n]), float(ref[n])
             worst[n] = max(worst[n], abs(a - b) / (abs(b) + 1e-6))
+            if step == 0:
+                first[n] = abs(a - b) / (abs(b) + 1e-6)
+                assert first[n] < 2e-5, (n, a, b)
             assert abs(a - b) <= 2e-6 + LOSS_RTOL * abs(b), (step, n, a, b)
     assert float(loss[names[0]]) < float(G["out/" + names[0]])         # and it trains
-    print("worst relative deviation over 60 steps:", {n: "%.1e" % w for n, w in worst.items()})
+    print("relative deviation at step 0:", {n: "%.1e" % w for n, w in first.items()},
+          "worst over 60 steps:", {n: "%.1e" % w for n, w in worst.items()})
 
 
 @pytest.mark.parametrize("name,kind", [("divae_tiny", "divae"), ("divst_tiny", "divst")])
