@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, result_dir, kind):
+def _worker(rank, world, port, result_dir, kind, backend="gloo"):
     import faulthandler
     # a rank that is still running after 100 s dumps every thread's stack and exits: the test then fails with the
     # place it was stuck at instead of hanging until the runner's own time limit
@@ -39,7 +39,12 @@ def _worker(rank, world, port, result_dir, kind):
     from laed_amd.models.sent_models import DiVAE, DiVST
 
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    if backend == "nccl":
+        os.environ["LAED_DP_FORCE"] = "1"          # keep the hooks / side stream / collectives on for a 1-rank group
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     parallel.init()
     G = load_golden(kind + "_mid")
     cfg = golden_config(G)
@@ -93,3 +98,12 @@ def test_dp_step_equals_reference_global_batch(tmp_path, world, kind):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
     assert sorted(os.listdir(str(tmp_path))) == ["ok%d" % r for r in range(world)]
+
+
+def test_dp_path_on_rccl_single_rank(tmp_path):
+    """The same step with backend "nccl" (RCCL) on a 1-rank group with the data-parallel machinery forced on: the
+    gradient hooks, the reducer's side stream and every collective run through RCCL as they do on the 8-GPU node (a
+    1-GPU box cannot host two RCCL ranks), and the result is still the reference's."""
+    port = _free_port()
+    mp.spawn(_worker, args=(1, port, str(tmp_path), "divae", "nccl"), nprocs=1, join=True)
+    assert os.listdir(str(tmp_path)) == ["ok0"]
