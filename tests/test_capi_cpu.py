@@ -29,6 +29,40 @@ def test_python_binding_covers_the_header():
     assert _lib.lib.laed_version() >= 100
 
 
+def test_binding_signatures_match_the_header():
+    """Every ctypes signature in laed_amd/_lib.py has the header's parameter count, and each parameter's ctypes kind
+    (pointer / int / int64 / uint64 / float / double) is the one the C declaration spells."""
+    from laed_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    decls = dict(re.findall(r"\b(laed_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+
+    def kind(param):
+        p = " ".join(param.split())
+        if "*" in p:
+            return ctypes.c_void_p
+        if p.startswith("uint64_t"):
+            return ctypes.c_uint64
+        if p.startswith("int64_t"):
+            return ctypes.c_int64
+        if p.startswith("int "):
+            return ctypes.c_int
+        if p.startswith("float "):
+            return ctypes.c_float
+        if p.startswith("double "):
+            return ctypes.c_double
+        raise AssertionError("unrecognised parameter %r" % p)
+
+    for name, (args, _res) in _lib._SIGS.items():
+        params = [q for q in decls[name].split(",") if q.strip() and q.strip() != "void"]
+        assert len(params) == len(args), (name, len(params), len(args))
+        for i, (q, a) in enumerate(zip(params, args)):
+            want = kind(q)
+            if want is ctypes.c_void_p:          # POINTER(c_double) etc. are pointers too
+                assert a is ctypes.c_void_p or a is ctypes.c_char_p or hasattr(a, "contents") or issubclass(a, ctypes._Pointer), (name, i)
+            else:
+                assert a is want, (name, i, q.strip(), a)
+
+
 def test_argument_validation_without_a_device():
     from laed_amd import _lib
     lib = _lib.lib
