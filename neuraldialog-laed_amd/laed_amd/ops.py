@@ -3,6 +3,8 @@
 Everything here runs on the HIP kernels of liblaed_hip.so; torch is used for device memory, streams and
 the autograd tape only.  Sequence tensors are time-major ([T,B,*]) at this level.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -110,6 +112,9 @@ def proj_chunk_rows(N, V, H=1024):
     2 blocks on each of its 256 CUs, so rows are chosen to make that a multiple of 512 tiles (8192 rows at
     H=1024) within ~2 GiB of workspace; small problems use one chunk."""
     ldl = proj_ldl(V)
+    forced = int(os.environ.get("LAED_PROJ_CHUNK_ROWS", "0"))      # experiment hook
+    if forced > 0:
+        return int(min(max(N, 1), forced))
     cap = max(1024, (1 << 29) // ldl)                       # rows that fit 2 GiB of fp32 workspace
     if N <= cap:
         return int(max(N, 1))
