@@ -14,7 +14,7 @@ buf0 = torch.empty(R, ldl, device="cuda")
 buf1 = torch.randn(R, ldl, device="cuda")
 dl = torch.randn(R, ldl, device="cuda")
 dh = torch.empty(R, H, device="cuda")
-side = torch.cuda.Stream()
+side = torch.cuda.Stream(priority=int(os.environ.get("SIDE_PRIO", "0")))
 
 
 def gemm():
