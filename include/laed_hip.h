@@ -132,6 +132,14 @@ int laed_gumbel_latent_bwd(const float* y, const float* dy, const float* log_qy,
 int laed_latent_stats_blocks(void);
 int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats, void* stream);
 int laed_latent_finalize(const float* stats, double B_global, int y, int k, float* scal, float* coef, void* stream);
+/* Allocation-free variant of laed_latent_stats.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate or bring a workspace -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same outputs as laed_latent_stats (bit for bit: same kernels, same fixed-order reduction); the block partials live
+ * in a file-scope __device__ array inside the library (2.1 MB per GPU, held until the process ends) whose per-device
+ * address is resolved once with hipGetSymbolAddress.  Limit: y*k <= 2048 (LAED_E_SIZE beyond it).  Calls nothing that
+ * allocates (no hipMalloc / hipFree / torch).  Call it with the stream's device current.  All calls on one GPU share
+ * the array: calls that overlap on one GPU (two streams) race -- serialise them. */
+int laed_latent_stats_noalloc(const float* log_qy, int64_t B, int y, int k, float* stats, void* stream);
 int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale, int use_mutual,
                     int64_t B, double B_global, int y, int k, float* dlog_qy, int accumulate, void* stream);
 

@@ -3,6 +3,7 @@
 // a row of k <= 64 classes lives on a W-lane sub-group of a wavefront (W = 16/32/64) and is reduced with
 // __shfl_xor, so one 64-lane wave handles 64/W rows per instruction.
 #include "laed_common.h"
+#include <mutex>
 #include <math.h>
 
 namespace {
@@ -331,6 +332,50 @@ extern "C" int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, f
     LAED_LAUNCH_CHECK("latent_stats");
     hipLaunchKernelGGL(latent_stats_combine_kernel, dim3((yk + 2 + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, yk + 2, stats);
     LAED_LAUNCH_CHECK("latent_stats_combine");
+    return 0;
+}
+
+// ---- allocation-free variant of laed_latent_stats (no counterpart in the reference; see include/laed_hip.h) ----------
+// The block partials ([STAT_BLOCKS][y*k + 2] floats) live in a file-scope device array instead of a caller workspace, so
+// callers that cannot allocate (HIP graph capture, tight serving loops) need to bring inputs and outputs only.  The
+// array's NAME is a host-side stand-in, not a device address: its address is resolved once per device with
+// hipGetSymbolAddress (with that device current) and only that pointer is ever handed to kernels.  Every GPU holds its
+// own copy (STAT_BLOCKS * (MAXE*256 + 2) floats = 2.1 MB) until the process ends.  Each call overwrites the partials it
+// later reads (nblk rows written, the same nblk rows read), so nothing has to start at zero; calls that overlap on one
+// GPU (two streams) share the array and race.
+static __device__ __align__(256) float scratch[STAT_BLOCKS * (MAXE * 256 + 2)];
+
+namespace {
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[64] = {nullptr};     // per device
+}
+
+extern "C" int laed_latent_stats_noalloc(const float* log_qy, int64_t B, int y, int k, float* stats, void* stream) {
+    LAED_CHECK_ARG(B > 0 && y > 0 && k > 0, "latent_stats_noalloc: bad size");
+    if ((int64_t)y * k > (int64_t)MAXE * 256)
+        return laed_fail(LAED_E_SIZE, "latent_stats_noalloc: y*k = %lld exceeds the built-in scratch (max y*k = %d)",
+                         (long long)y * k, MAXE * 256);
+    LAED_CHECK_ARG(log_qy && stats, "latent_stats_noalloc: null pointer");
+    int dev = 0;
+    LAED_HIP_TRY(hipGetDevice(&dev));
+    LAED_CHECK_ARG(dev >= 0 && dev < 64, "latent_stats_noalloc: device index %d out of range", dev);
+    float* ws;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (g_scratch_ptr[dev] == nullptr) {      // set-up, once per device, with that device current
+            void* sym = nullptr;
+            LAED_HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+            if (sym == nullptr) return laed_fail(LAED_E_BADARG, "latent_stats_noalloc: hipGetSymbolAddress returned NULL");
+            g_scratch_ptr[dev] = (float*)sym;
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    const int yk = y * k;
+    const int nblk = (int)(B < STAT_BLOCKS ? B : STAT_BLOCKS);
+    hipLaunchKernelGGL(latent_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, B, yk, k, ws);
+    LAED_LAUNCH_CHECK("latent_stats (noalloc)");
+    hipLaunchKernelGGL(latent_stats_combine_kernel, dim3((yk + 2 + 3) / 4), dim3(256), 0, (hipStream_t)stream, ws, nblk, yk + 2, stats);
+    LAED_LAUNCH_CHECK("latent_stats_combine (noalloc)");
     return 0;
 }
 

@@ -40,6 +40,7 @@ _SIGS = {
     "laed_gumbel_latent_bwd": ([_p, _p, _p, _p, _i64, _i, _f, _p, _p], _i),
     "laed_latent_stats_blocks": ([], _i),
     "laed_latent_stats": ([_p, _i64, _i, _i, _p, _p, _p], _i),
+    "laed_latent_stats_noalloc": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_latent_finalize": ([_p, _d, _i, _i, _p, _p, _p], _i),
     "laed_latent_bwd": ([_p, _p, _p, _i, _i64, _d, _i, _i, _p, _i, _p], _i),
     "laed_avg_log_fwd": ([_p, _d, _i, _p, _p], _i),
