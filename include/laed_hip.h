@@ -106,6 +106,24 @@ int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh,
                  float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                  float* dh0, int accumulate_w, float* ws, int64_t ws_floats, void* stream);
 
+/* The same two calls with a CU budget for the persistent small-batch kernels (B <= 64): those launches need ALL their
+ * workgroups (H/4 forward, H/8 backward, one per CU) resident at once, so they are taken only when the grid fits
+ * min(cu_budget, the device's CU count); otherwise the recurrence runs as per-step launches of the same core.
+ * cu_budget = 0 means the whole device (what laed_gru_fwd / laed_gru_bwd pass).  A caller that runs two recurrences
+ * side by side on two streams (DI-VST's two decoders, sent_models.py:397-405) passes half the CU count to each.
+ * laed_gru_persist_timeouts: number of bounded in-kernel waits that timed out on the current device since the process
+ * started (a grid that could not become co-resident poisons its outputs with NaN and bumps this counter); synchronous
+ * 4-byte device read -- call it where the host synchronises anyway. */
+int laed_gru_fwd_cus(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                     const float* h0, int T, int B, int E, int H,
+                     float* hbuf, float* gates, float* hn, float* ws, int64_t ws_floats, int cu_budget, void* stream);
+int laed_gru_bwd_cus(const float* x, const float* w_ih, const float* w_hh,
+                     const float* hbuf, float* gates, const float* hn,
+                     const float* dout, const float* dhT, int T, int B, int E, int H,
+                     float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                     float* dh0, int accumulate_w, float* ws, int64_t ws_floats, int cu_budget, void* stream);
+int laed_gru_persist_timeouts(unsigned* out_host);
+
 /* ------------------------------------------------------------------------------------------
  * Posterior / Gumbel-softmax latent (rows R = B*y_size, k classes, k <= 64).
  *   log_qy = log_softmax(logits)                         sent_models.py:110-111 ("Hidden2Discrete")

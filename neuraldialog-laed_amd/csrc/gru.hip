@@ -388,6 +388,13 @@ int laed_gru_step_impl(const float* hprev, const float* w_hh, const float* b_hh,
 extern "C" int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                             const float* h0, int T, int B, int E, int H,
                             float* hbuf, float* gates, float* hn, float* ws, int64_t ws_floats, void* stream_) {
+    return laed_gru_fwd_cus(x, w_ih, w_hh, b_ih, b_hh, h0, T, B, E, H, hbuf, gates, hn, ws, ws_floats, 0, stream_);
+}
+
+extern "C" int laed_gru_fwd_cus(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                const float* h0, int T, int B, int E, int H,
+                                float* hbuf, float* gates, float* hn, float* ws, int64_t ws_floats, int cu_budget,
+                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAED_CHECK_ARG(T > 0 && B > 0 && E > 0 && H > 0, "gru_fwd: non-positive dimension");
     LAED_CHECK_ARG(x && w_ih && w_hh && b_ih && b_hh && hbuf && gates, "gru_fwd: null pointer");
@@ -406,7 +413,7 @@ extern "C" int laed_gru_fwd(const float* x, const float* w_ih, const float* w_hh
     LAED_TRY(laed_sgemm_impl(false, true, T * B, 3 * H, E, x, E, w_ih, E, gates, 3 * H, b_ih, false, nullptr, false, stream));
     // small batches: packed-operand step kernels (gru_small.hip)
     if (ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_fwd_ws(B, H))
-        return laed_gru_small_fwd(w_hh, b_hh, hbuf, gates, hn, T, B, H, ws, stream);
+        return laed_gru_small_fwd(w_hh, b_hh, hbuf, gates, hn, T, B, H, ws, cu_budget, stream);
     for (int t = 0; t < T; ++t) {
         GruStepArgs a;
         a.hprev = hbuf + (int64_t)t * BH;
@@ -427,6 +434,15 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
                             const float* dout, const float* dhT, int T, int B, int E, int H,
                             float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                             float* dh0, int accumulate_w, float* ws, int64_t ws_floats, void* stream_) {
+    return laed_gru_bwd_cus(x, w_ih, w_hh, hbuf, gates, hn, dout, dhT, T, B, E, H, dgh, dx, dw_ih, dw_hh, db_ih, db_hh, dh0,
+                            accumulate_w, ws, ws_floats, 0, stream_);
+}
+
+extern "C" int laed_gru_bwd_cus(const float* x, const float* w_ih, const float* w_hh,
+                                const float* hbuf, float* gates, const float* hn,
+                                const float* dout, const float* dhT, int T, int B, int E, int H,
+                                float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                                float* dh0, int accumulate_w, float* ws, int64_t ws_floats, int cu_budget, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LAED_CHECK_ARG(T > 0 && B > 0 && E > 0 && H > 0, "gru_bwd: non-positive dimension");
     LAED_CHECK_ARG(x && w_ih && w_hh && hbuf && gates && hn && dgh && dw_ih && dw_hh && db_ih && db_hh && dh0,
@@ -456,7 +472,7 @@ extern "C" int laed_gru_bwd(const float* x, const float* w_ih, const float* w_hh
     int nparts = 0;
     // small batches: one fused launch per step (gru_small.hip) over a packed copy of W_hh^T at the front of ws
     const bool small = ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_bwd_ws(B, H);
-    if (small) LAED_TRY(laed_gru_small_bwd(w_hh, hbuf, hn, dout, gates, dgh, dh0, T, B, H, ws, stream));
+    if (small) LAED_TRY(laed_gru_small_bwd(w_hh, hbuf, hn, dout, gates, dgh, dh0, T, B, H, ws, cu_budget, stream));
     for (int t = small ? -1 : T - 1; t >= 0; --t) {
         GruBwdStepArgs a;
         a.parts = ws;

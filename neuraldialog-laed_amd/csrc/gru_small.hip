@@ -240,6 +240,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS4 = 16;             // float4 slots per quad in the LDS slab (12 used: keeps the kq groups on disjoint banks)
 constexpr unsigned SPIN_LIMIT = 4000000;    // ~4 s of polling: only a grid that can never become resident gets there
 
+// Sticky per-device count of timed-out waits (besides the per-call sync[1] word): the host reads it with
+// laed_gru_persist_timeouts() whenever it next synchronises anyway (e.g. when it sees a NaN loss), so a poisoned output
+// can be told from an ordinary numerical blow-up.  Written with a vector atomic (agent scope); never reset by kernels.
+__device__ unsigned g_persist_timeouts = 0;
+
 template <int RT, int NC, int WS>
 __device__ __forceinline__ void persist_core(__amdgpu_buffer_rsrc_t x, const float* __restrict__ slab, int ngrp, int wave, int lane,
                                              f32x4 (&acc)[RT]) {
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > SPIN_LIMIT) {
                         __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&g_persist_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_dead = 1;
                         break;
                     }
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > SPIN_LIMIT) {
                         __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&g_persist_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_dead = 1;
                         break;
                     }
@@ -549,6 +556,27 @@ void launch_rt(int B, dim3 grid, hipStream_t stream, const A& a, K1 k1, K2 k2, K
 
 }   // namespace
 
+// CUs a persistent grid may fill: the device's multiprocessor count (queried once per device; 256 on MI355X, fewer on
+// a partitioned or CU-masked device), capped by the caller's budget (cu_budget > 0).
+int laed_persist_cu_limit(int cu_budget) {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+        cus[dev] = n;
+    }
+    return (cu_budget > 0 && cu_budget < cus[dev]) ? cu_budget : cus[dev];
+}
+
+// Timed-out waits of the persistent kernels on the current device since the process started (synchronous read).
+extern "C" int laed_gru_persist_timeouts(unsigned* out_host) {
+    LAED_CHECK_ARG(out_host != nullptr, "gru_persist_timeouts: null pointer");
+    LAED_HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_persist_timeouts), sizeof(unsigned), 0, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // Row groups: up to 64 rows one group (padded to whole 16-row MFMA tiles); larger batches run as groups of 64 rows in
 // blockIdx.y of the per-step kernels, each group re-reading the packed W_hh out of L2.
 static int small_groups(int B) { return B <= 64 ? 1 : (B + 63) / 64; }
@@ -576,7 +604,7 @@ int64_t laed_gru_small_bwd_ws(int B, int H) {
 
 // forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
 int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
-                       float* ws, hipStream_t stream) {
+                       float* ws, int cu_budget, hipStream_t stream) {
     const int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wp = ws;
@@ -588,7 +616,10 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
     // default: one persistent launch with LDS-resident W_hh (4.9 vs 6.3 us per step + launch gaps at B = 30, H = 512);
     // LAED_GRU_PERSIST=0 selects the per-step launches below
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
-    if (persist && NG == 1 && H / UF <= 256) {
+    // every workgroup of the persistent grid must be resident at once, one per CU: take that path only when the grid
+    // fits the CUs this call may count on (the device's CU count, or the caller's share of it when a second stream
+    // may hold a persistent grid of its own at the same time)
+    if (persist && NG == 1 && H / UF <= laed_persist_cu_limit(cu_budget)) {
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP);
         hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
         if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
@@ -629,7 +660,7 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
 // backward recurrence over all T steps (gate gradients + dh chain); dh0 holds dh_T on entry and dh_0 on return.
 // ws: laed_gru_small_bwd_ws floats, 16-byte aligned.
 int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, float* gates, float* dgh,
-                       float* dh0, int T, int B, int H, float* ws, hipStream_t stream) {
+                       float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream) {
     const int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wpT = ws;
@@ -637,7 +668,7 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
     hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT);
     LAED_LAUNCH_CHECK("gru_small pack_w_bwd");
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
-    if (persist && NG == 1 && H / UB <= 256) {
+    if (persist && NG == 1 && H / UB <= laed_persist_cu_limit(cu_budget)) {
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * BP);
         hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
         if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");

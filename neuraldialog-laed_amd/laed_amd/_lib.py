@@ -32,6 +32,9 @@ _SIGS = {
     "laed_dropout_keep_mask": ([_p, _i64, _f, _u64, _u64, _p], _i),
     "laed_uniform": ([_p, _i64, _u64, _u64, _p], _i),
     "laed_gru_fwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i64, _p], _i),
+    "laed_gru_fwd_cus": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p], _i),
+    "laed_gru_bwd_cus": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _p], _i),
+    "laed_gru_persist_timeouts": ([ctypes.POINTER(ctypes.c_uint)], _i),
     "laed_gru_fwd_workspace": ([_i, _i, _i, _i], _i64),
     "laed_gru_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _p], _i),
     "laed_gru_bwd_workspace": ([_i, _i, _i, _i], _i64),

@@ -72,7 +72,11 @@ class BaseModel(nn.Module):
         if config.op not in ('adam', 'sgd', 'rmsprop'):
             return None                                             # the reference falls through and returns None
         trainable = [p for p in self.parameters() if p.requires_grad]
+        old = getattr(self, "_grad_reducer", None)
+        if old is not None:                      # e.g. the optimizer rebuilt after flush_valid (main.py:106-110): the
+            old.close()                          # previous reducer's hooks must not reduce every gradient a second time
         reducer = parallel.GradReducer(trainable) if parallel.group() is not None else None
+        object.__setattr__(self, "_grad_reducer", reducer)
         if config.op == 'adam':
             logger.info("Use adam")
             return optim.FusedAdam(trainable, lr=config.init_lr, reducer=reducer)

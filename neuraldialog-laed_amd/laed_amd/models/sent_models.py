@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import criterions, nn_lib
+from .. import criterions, nn_lib, ops
 from ..enc2dec.base_modules import BOS, EOS, PAD
 from ..enc2dec.decoders import GEN, DecoderRNN
 from ..enc2dec.encoders import EncoderRNN
@@ -221,16 +221,17 @@ class DiVST(_SentBase):
                 self._side_stream = torch.cuda.Stream(device=dec_init_state.device)
             side = self._side_stream
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for t in (dec_init_state, next_utts, next_labels):
-                    t.record_stream(side)
-                next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state, mode=mode,
+            with ops.concurrent_streams(2):          # each decoder's persistent recurrence may count on half the CUs
+                with torch.cuda.stream(side):
+                    for t in (dec_init_state, next_utts, next_labels):
+                        t.record_stream(side)
+                    next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state,
+                                                                       mode=mode, gen_type=gen_type, beam_size=self.beam_size)
+                    next_nll = self.nll_loss(next_dec_outs, next_labels)
+                    next_nll.record_stream(cur)
+                prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
                                                                    gen_type=gen_type, beam_size=self.beam_size)
-                next_nll = self.nll_loss(next_dec_outs, next_labels)
-                next_nll.record_stream(cur)
-            prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
-                                                               gen_type=gen_type, beam_size=self.beam_size)
-            prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
+                prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
             cur.wait_stream(side)
         else:
             prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,

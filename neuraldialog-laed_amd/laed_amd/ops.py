@@ -279,6 +279,43 @@ def linear(x, W, b=None):
     return LinearFunction.apply(x, W, b)
 
 
+_CU_SHARE = {"streams": 1}
+
+
+class concurrent_streams(object):
+    """`with ops.concurrent_streams(2):` -- recurrences issued inside may run side by side on that many HIP streams
+    (DI-VST's two decoders).  The persistent small-batch GRU kernels need their whole grid resident at once, so each
+    gets 1/n of the device's CUs as its budget (forward and, recorded on the tape, backward); a grid that does not fit
+    its share runs as per-step launches instead of waiting for CUs the other stream's grid holds."""
+
+    def __init__(self, n):
+        self.n = max(1, int(n))
+
+    def __enter__(self):
+        self.prev = _CU_SHARE["streams"]
+        _CU_SHARE["streams"] = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _CU_SHARE["streams"] = self.prev
+        return False
+
+
+def _cu_budget(device):
+    n = _CU_SHARE["streams"]
+    if n <= 1:
+        return 0                                            # the whole device
+    return max(1, torch.cuda.get_device_properties(device).multi_processor_count // n)
+
+
+def gru_persist_timeouts():
+    """Timed-out in-kernel waits of the persistent GRU kernels on the current device (synchronises the device)."""
+    import ctypes
+    out = ctypes.c_uint(0)
+    check(lib.laed_gru_persist_timeouts(ctypes.byref(out)), "laed_gru_persist_timeouts")
+    return int(out.value)
+
+
 class GRUFunction(torch.autograd.Function):
     """x[T,B,E] (time-major) -> out[T,B,H], hT[B,H]."""
 
@@ -294,8 +331,9 @@ class GRUFunction(torch.autograd.Function):
         h0c = _f32c(h0) if h0 is not None else None
         ws_n = int(lib.laed_gru_fwd_workspace(T, B, E, H))         # packed operands of the small-batch step kernels
         ws = workspace("gru_ws", ws_n, dev) if ws_n > 0 else None
-        check(lib.laed_gru_fwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(h0c), T, B, E, H,
-                               ptr(hbuf), ptr(gates), ptr(hn), ptr(ws), ws_n, stream()), "laed_gru_fwd")
+        ctx.cu_budget = _cu_budget(dev)
+        check(lib.laed_gru_fwd_cus(ptr(x), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(h0c), T, B, E, H,
+                                   ptr(hbuf), ptr(gates), ptr(hn), ptr(ws), ws_n, ctx.cu_budget, stream()), "laed_gru_fwd")
         ctx.save_for_backward(x, w_ih, w_hh, hbuf, gates, hn)
         ctx.has_h0 = h0 is not None
         out = hbuf[1:]
@@ -321,9 +359,9 @@ class GRUFunction(torch.autograd.Function):
         ws_n = int(lib.laed_gru_bwd_workspace(T, B, E, H))         # split-K scratch (+ transposed operands in bf16x3 mode)
         ws = workspace("gru_ws", ws_n, dev)
         # NOTE: overwrites the saved `gates` (r,z,n -> d gi): the tape is single-use, like cuDNN's reserve space
-        check(lib.laed_gru_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(hbuf), ptr(gates), ptr(hn), ptr(dout), ptr(dhT),
-                               T, B, E, H, ptr(dgh), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), 0,
-                               ptr(ws), ws_n, stream()), "laed_gru_bwd")
+        check(lib.laed_gru_bwd_cus(ptr(x), ptr(w_ih), ptr(w_hh), ptr(hbuf), ptr(gates), ptr(hn), ptr(dout), ptr(dhT),
+                                   T, B, E, H, ptr(dgh), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), 0,
+                                   ptr(ws), ws_n, ctx.cu_budget, stream()), "laed_gru_bwd")
         return dx, dw_ih, dw_hh, db_ih, db_hh, (dh0 if ctx.has_h0 else None)
 
 

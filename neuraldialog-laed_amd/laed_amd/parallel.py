@@ -62,43 +62,94 @@ def shard_rows(n):
 
 
 class GradReducer(object):
-    """Overlapped gradient all-reduce (SUM) for a list of parameters.
+    """Overlapped, bucketed gradient all-reduce (SUM) for a list of parameters.
 
-    A hook on each parameter fires when its .grad has been accumulated in backward; the reduce is enqueued on
-    a dedicated stream that waits on the compute stream's current position, so collectives for early-ready
-    gradients (the vocabulary projection) run while the rest of backward computes.  `wait()` joins the streams.
+    A hook on each parameter fires when its .grad has been accumulated in backward.  Gradients are reduced in the
+    order backward produces them (decoder.project.weight -- 74 % of the bytes at the scaled shape -- comes first and
+    its reduce overlaps the decoder / encoder GRU backward):
+      * a gradient of at least `big_bytes` is all-reduced in place, on its own (no copy);
+      * smaller ones (biases, q_y, the connector, ...) are coalesced: copied into one flat fp32 buffer, reduced with ONE
+        collective once `bucket_bytes` are pending (or at wait()), and the parameters' .grad are then re-pointed at their
+        slices of the reduced buffer (no copy back).
+    Collectives are enqueued on a dedicated stream that waits for each producer stream, so they run beside the rest of
+    backward; `wait()` joins the streams.  `close()` removes the hooks (a model that builds a second optimizer must
+    not leave the first reducer's hooks live: every gradient would be summed twice).
     """
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=32 << 20, big_bytes=8 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.enabled = _ENABLED
-        self.handles = []
         self.bucket_bytes = bucket_bytes
-        self._pending = []
+        self.big_bytes = big_bytes
+        self._pending = []                      # (param, producer event) of small gradients not yet flushed
         self._pending_bytes = 0
+        self._hooks = []
+        self.collectives = 0                    # issued since construction (tests / rehearsal bookkeeping)
+        self.stream = None
         if not self.enabled:
             return
-        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.stream = torch.cuda.Stream() if (torch.cuda.is_available() and any(p.is_cuda for p in self.params)) else None
         for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def close(self):
+        """Flush what is pending, join the side stream and remove the hooks."""
+        if self.enabled:
+            self.wait()
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.enabled = False
+
+    def _reduce(self, t, events):
+        self.collectives += 1
+        if self.stream is not None and t.is_cuda:
+            # each gradient was finished on the stream its hook ran on (DI-VST's two decoders run, and are replayed by
+            # autograd, on two streams): wait for every producer, not only for the stream that triggered the flush
+            for ev in events:
+                if ev is not None:
+                    self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                t.record_stream(self.stream)
+                dist.all_reduce(t, group=_GROUP)
+        else:                                   # CPU / gloo test path
+            dist.all_reduce(t, group=_GROUP)
 
     def _flush(self):
         if not self._pending:
             return
         pending, self._pending, self._pending_bytes = self._pending, [], 0
-        if self.stream is not None:
-            # each gradient was finished on the stream its hook ran on (DI-VST's two decoders run, and are replayed by
-            # autograd, on two streams): wait for every producer, not only for the stream that triggered the flush
+        if len(pending) == 1:
+            p, ev = pending[0]
+            self._reduce(p.grad, [ev])
+            return
+        g0 = pending[0][0].grad
+        n = sum(p.grad.numel() for p, _ in pending)
+        side = self.stream is not None and g0.is_cuda
+        if side:
             for _, ev in pending:
                 if ev is not None:
                     self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
-                for g, _ in pending:
+        ctx = torch.cuda.stream(self.stream) if side else _Null()
+        with ctx:
+            flat = torch.empty(n, device=g0.device, dtype=g0.dtype)
+            off = 0
+            views = []
+            for p, _ in pending:
+                g = p.grad
+                k = g.numel()
+                v = flat[off:off + k].view(g.shape)
+                v.copy_(g)
+                if side:
                     g.record_stream(self.stream)
-                    dist.all_reduce(g, group=_GROUP)
-        else:                                   # CPU / gloo test path
-            for g, _ in pending:
-                dist.all_reduce(g, group=_GROUP)
+                views.append((p, v))
+                off += k
+            self.collectives += 1
+            dist.all_reduce(flat, group=_GROUP)
+        if side:
+            flat.record_stream(torch.cuda.current_stream())
+        for p, v in views:
+            p.grad = v                          # consumers (the optimizer) join the side stream in wait() first
 
     def _hook(self, p):
         g = p.grad
@@ -106,8 +157,12 @@ class GradReducer(object):
         if self.stream is not None and g.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-        self._pending.append((g, ev))
-        self._pending_bytes += g.numel() * g.element_size()
+        nbytes = g.numel() * g.element_size()
+        if nbytes >= self.big_bytes or g.dtype != torch.float32 or not g.is_contiguous():
+            self._reduce(g, [ev])
+            return
+        self._pending.append((p, ev))
+        self._pending_bytes += nbytes
         if self._pending_bytes >= self.bucket_bytes:
             self._flush()
 
@@ -118,3 +173,11 @@ class GradReducer(object):
         self._flush()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class _Null(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

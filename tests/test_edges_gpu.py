@@ -187,3 +187,63 @@ def test_empty_row_sets_at_the_c_abi():
     assert out.shape == (0, E)
     c = ops.sgemm(torch.empty(0, H, device="cuda"), W, transB=True)
     assert c.shape == (0, V)
+
+
+def test_divst_two_streams_wide_decoder_does_not_wait_for_cus():
+    """DI-VST with dec_cell_size = 1024 at the script batch (60): each decoder's persistent recurrence would need
+    1024/4 = 256 workgroups resident at once, one per CU -- two of them side by side on the model's two streams can never
+    both fit the chip's 256 CUs.  Inside `ops.concurrent_streams(2)` each recurrence gets half the CUs as its budget and
+    runs as per-step launches instead; nothing waits, nothing is poisoned with NaN, and losses and gradients equal the
+    oracle's (sent_models.py:363-442)."""
+    import numpy as np
+    import torch
+    from argparse import Namespace
+    from laed_amd import ops
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from laed_amd.models.sent_models import DiVST
+    from oracle import laed_oracle as O
+    from helpers import rel_err
+    V, E, He, Hd, Y, K, T, B = 300, 32, 64, 1024, 4, 5, 9, 60
+    cfg = Namespace(embed_size=E, max_utt_len=T, num_layer=1, dropout=0.0, enc_cell_size=He, dec_cell_size=Hd,
+                    rnn_cell='gru', max_dec_len=T, use_attn=False, beam_size=4, utt_type='rnn', bi_enc_cell=False,
+                    attn_type='cat', fix_batch=False, y_size=Y, k=K, use_gpu=True, avg_type='word', use_mutual=True,
+                    use_reg_kl=True, train_prior=False, init_lr=0.001, op='adam', batch_size=B)
+
+    class Corpus(object):
+        vocab = ['<pad>', '<unk>', '<s>', '</s>'] + ['w%d' % i for i in range(4, V)]
+        rev_vocab = {w: i for i, w in enumerate(vocab)}
+
+    torch.manual_seed(3)
+    model = DiVST(Corpus(), cfg).cuda().train()
+    assert model.two_streams
+    rs = np.random.RandomState(8)
+
+    def utts():
+        a = rs.randint(4, V, size=(B, T)).astype(np.int32)
+        a[:, 0], a[:, -1] = 2, 3
+        a[::5, T - 3:] = 0
+        a[::5, T - 4] = 3
+        return a
+    outs, prevs, nexts = utts(), utts(), utts()
+    u = rs.uniform(size=(B * Y, K)).astype(np.float32)
+    ud = torch.from_numpy(u).cuda()
+    model.cat_connector.sample_uniform = lambda logits: ud
+    before = ops.gru_persist_timeouts()
+    loss = model({"outputs": outs, "output_lens": [T] * B, "prevs": prevs, "nexts": nexts}, mode=TEACH_FORCE)
+    model.backward(0, loss)
+    torch.cuda.synchronize()
+    assert ops.gru_persist_timeouts() == before
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for k in list(P):
+        if k.endswith("decoder.embedding.weight"):
+            P[k] = P["embedding.weight"]
+        else:
+            P[k].requires_grad_(True)
+    ref = O.divst_forward(P, cfg, outs, prevs, nexts, u, training=True)
+    ref["total"].backward()
+    for k in ("prev_nll", "next_nll", "reg_kl"):
+        a, b = float(loss[k].detach()), float(ref[k].detach())
+        assert np.isfinite(a) and abs(a - b) <= 1e-7 + 1e-4 * abs(b), (k, a, b)
+    for n, p in model.named_parameters():
+        if P[n].grad is not None:
+            assert rel_err(p.grad.cpu(), P[n].grad) < 2e-4, (n, rel_err(p.grad.cpu(), P[n].grad))

@@ -1,7 +1,7 @@
 """world_size-2 data-parallel host path on CPU (gloo): gradient reducer, sharding, and the two forward
 exchanges (global non-PAD count for 'word' NLL, batch-mean posterior for BPR) reproduce single-process values."""
+import datetime
 import os
-import socket
 import sys
 
 import numpy as np
@@ -12,15 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def _worker(rank, world, port, result_dir):
+def _worker(rank, world, result_dir):
     for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -30,19 +22,44 @@ def _worker(rank, world, port, result_dir):
     from laed_amd import criterions, parallel
     from oracle import laed_oracle as O
 
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    # file:// rendezvous: no port to pick (a probed-then-released TCP port can be taken before rank 0 binds it), and a
+    # rank that never arrives fails the group in 60 s instead of the 30-minute default
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(result_dir, "rdzv"), rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60))
     parallel.init()
     assert parallel.world_size() == world and parallel.rank() == rank and parallel.group() is not None
     assert parallel.shard_rows(12) == (rank * 6, rank * 6 + 6)
 
     # 1. overlapped gradient reducer: SUM over ranks, fired from post-accumulate-grad hooks
     torch.manual_seed(0)
-    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
-    red = parallel.GradReducer(params, bucket_bytes=16)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(64, 8)),
+              torch.nn.Parameter(torch.randn(3))]
+    # big_bytes = 1 KiB: the [64,8] tensor (2 KiB) is reduced on its own, in place; the three small ones are coalesced
+    # into one flat buffer (3 + 7 + 15 floats reach the 64-byte bucket size with the last of them)
+    red = parallel.GradReducer(params, bucket_bytes=64, big_bytes=1024)
     sum((p * float(rank + 1)).sum() for p in params).backward()
     red.wait()
     for p in params:
-        assert torch.allclose(p.grad, torch.full_like(p, 3.0))
+        assert torch.allclose(p.grad, torch.full_like(p, 3.0)), p.shape
+    assert red.collectives == 2, red.collectives          # 4 gradient tensors, 2 collectives
+    # a second optimizer for the same model (engine.train rebuilds it after flush_valid, main.py:106-110) must not leave
+    # the first reducer's hooks live: the reduced gradient is world_size x the local one, not world_size squared
+    from laed_amd.models.model_bases import BaseModel
+
+    class Tiny(BaseModel):
+        def __init__(self):
+            super(Tiny, self).__init__(Namespace(use_gpu=False))
+            self.w = torch.nn.Parameter(torch.ones(4, 4))
+
+    tiny = Tiny()
+    cfg_opt = Namespace(op="adam", init_lr=1e-3)
+    opt1 = tiny.get_optimizer(cfg_opt)
+    opt2 = tiny.get_optimizer(cfg_opt)
+    assert opt1.reducer is not opt2.reducer and not opt1.reducer.enabled and opt2.reducer.enabled
+    (tiny.w * float(rank + 1)).sum().backward()
+    opt2.reducer.wait()
+    assert torch.allclose(tiny.w.grad, torch.full((4, 4), 3.0)), tiny.w.grad
+    opt2.reducer.close()
 
     # 2. sharded loss terms == single-process global-batch values (reference golden)
     G = load_golden("divae_mid")
@@ -76,6 +93,5 @@ def _worker(rank, world, port, result_dir):
 
 
 def test_data_parallel_host_path_world2(tmp_path):
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(str(tmp_path))) == ["ok0", "ok1"]
