@@ -127,7 +127,17 @@ def flops_per_step(V, E, H, y, k, T, B, dec_positions=None):
     return 3.0 * (B * T * f_enc + B * dp * f_dec + B * f_seq)
 
 
-def cpu_baseline(V, E, H, y, k, T, sample_b, steps=2):
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(V, E, H, y, k, T, sample_b, steps=2, warmup=1):
     """Oracle nn.Module DiVAE (== the reference's stock-torch CPU path) on `sample_b` sequences of the workload."""
     from oracle.laed_oracle import OracleDiVAE
     torch.manual_seed(0)
@@ -144,7 +154,8 @@ def cpu_baseline(V, E, H, y, k, T, sample_b, steps=2):
         res = model(batch, u)
         res["total"].backward()
         opt.step()
-    step()                                    # warm-up
+    for _ in range(warmup):
+        step()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -165,6 +176,10 @@ def main():
     ap.add_argument("--gemm-mode", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32 = exact fp32 MFMA everywhere (default); bf16x3 = opt-in split-bf16 x W^T products")
     ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform"], help="interior token id distribution")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1: nccl = RCCL over xGMI (one rank per GPU); gloo = REHEARSAL of "
+                         "the N>1 code path with every rank on the GPUs that exist (ranks share cuda:0 on a 1-GPU box) -- "
+                         "not a scaling measurement")
     ap.add_argument("--phase", default="B", choices=["A", "B"],
                     help="AE-fixed / ST-fixed: A = recognition-network pretraining (before freeze_step), "
                          "B = encoder-decoder training with the recognition network frozen (after it)")
@@ -172,6 +187,9 @@ def main():
     global IDS
     IDS = args.ids
 
+    if os.environ.get("LAED_BENCH_WATCHDOG"):                # seconds: dump every thread's stack and exit (hang diagnosis)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LAED_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -180,7 +198,12 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); RCCL needs one rank per GPU "
+                         "(--backend gloo rehearses the N>1 path on fewer GPUs)" % (local_rank, ndev))
+    device_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(device_index)
 
     import torch.distributed as dist
     from laed_amd import parallel
@@ -190,10 +213,17 @@ def main():
     from laed_amd.models.dialog_models import AeED, StED
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
+                                    timeout=datetime.timedelta(seconds=600))
+        else:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
         parallel.init()
 
     from laed_amd import ops as _ops
+    if world > ndev:                                         # gloo rehearsal: several ranks per GPU
+        _ops.set_device_sharers((world + ndev - 1) // ndev)
     V, E, H, y, k, T, GB = SHAPES[args.workload]
     if args.global_batch:
         GB = args.global_batch
@@ -360,6 +390,9 @@ def main():
             "encoder_tokens_per_s": main_res["encoder_tokens_per_s"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == "fp32" else "f32 (x W^T products as split-bf16 bf16x3, fp32 accumulate)",
             "data": "synthetic",
+            **({"rehearsal": "backend gloo, %d ranks on %d GPU(s): exercises the N>1 code path (sharding, forward "
+                             "exchanges, bucketed gradient all-reduce); NOT a scaling number" % (world, ndev)}
+               if (world > 1 and args.backend == "gloo") else {}),
             "config": {"workload": args.workload, "ids": args.ids, "vocab": V, "embed": E, "hidden": H, "y_size": y, "k": k,
                        "seq_len": T, "global_batch": GB, "per_gpu_batch": per, "parallelism": "dp%d" % world,
                        "tokens_per_step": tokens_per_step,
@@ -374,20 +407,32 @@ def main():
                                "tests pass, tests/test_bf16x3_mode_gpu.py). NOT the headline `value`, which is exact fp32.")
             out["split_bf16_mode"] = alt_res
         if world == 1 and args.cpu_sample > 0 and args.workload in ("S-fixed", "P-fixed"):
-            # thread sweep: 1 thread on a quarter of the sample, then half and all of this job's cores
+            # thread sweep: 1 thread on a quarter of the sample, then half and all of this job's cores;
+            # the record run is then 2 warm-ups + 5 timed steps at the best thread count
             nmax = int(os.environ.get("OMP_NUM_THREADS", "0")) or torch.get_num_threads()
             sweep = []
-            for nt, nseq, nsteps in ((1, max(4, args.cpu_sample // 4), 1), (max(1, nmax // 2), args.cpu_sample, 2),
-                                     (nmax, args.cpu_sample, 2)):
+            for nt, nseq in ((1, max(4, args.cpu_sample // 4)), (max(1, nmax // 2), args.cpu_sample), (nmax, args.cpu_sample)):
                 torch.set_num_threads(nt)
-                tps, dt = cpu_baseline(V, E, H, y, k, T, nseq, steps=nsteps)
+                tps, dt = cpu_baseline(V, E, H, y, k, T, nseq, steps=1, warmup=1)
                 sweep.append({"cores": nt, "value": round(tps, 1), "ms_per_step": round(dt * 1e3, 1), "sequences": nseq})
             best = max(sweep, key=lambda r: r["value"])
-            out["cpu_baseline"] = {"value": best["value"], "unit": "tokens/s", "cores": best["cores"],
-                                   "kind": "port", "ms_per_step": best["ms_per_step"],
-                                   "sample": "%s shape, %d sequences/step (same step order), 1 warm-up + %d timed steps; "
-                                             "best of the thread sweep" % (args.workload, best["sequences"], 2),
+            torch.set_num_threads(best["cores"])
+            nseq = GB if args.workload == "P-fixed" else args.cpu_sample      # P shape: the full 30-sequence step
+            tps, dt = cpu_baseline(V, E, H, y, k, T, nseq, steps=5, warmup=2)
+            out["cpu_baseline"] = {"value": round(tps, 1), "unit": "tokens/s", "cores": best["cores"],
+                                   "kind": "port", "ms_per_step": round(dt * 1e3, 1), "cpu_model": cpu_model_name(),
+                                   "sample": "%s shape, %d sequences/step (same step order: zero_grad, forward, backward, "
+                                             "Adam), 2 warm-ups + 5 timed steps at the best thread count of the sweep"
+                                             % (args.workload, nseq),
                                    "thread_sweep": sweep}
+            if args.workload == "S-fixed":
+                # SURVEY.md 8d's CPU reference of record: the reference's own script shape (P: ptb-utt.py defaults,
+                # B = 30), full step, 2 warm-ups + 5 timed steps
+                Vp, Ep, Hp, yp, kp, Tp, Bp = SHAPES["P-fixed"]
+                tps_p, dt_p = cpu_baseline(Vp, Ep, Hp, yp, kp, Tp, Bp, steps=5, warmup=2)
+                out["cpu_baseline"]["p_shape_full_step"] = {
+                    "workload": "P-fixed (V=10002, H=512, B=30, T=40)", "value": round(tps_p, 1), "unit": "tokens/s",
+                    "ms_per_step": round(dt_p * 1e3, 1), "cores": best["cores"], "warmup": 2, "steps": 5}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
 // h_{t-1} of a workgroup's own units stays in registers.  Needs all H/UF workgroups resident at once (H/UF <= 256).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS4 = 16;             // float4 slots per quad in the LDS slab (12 used: keeps the kq groups on disjoint banks)
-constexpr unsigned SPIN_LIMIT = 4000000;    // ~4 s of polling: only a grid that can never become resident gets there
+constexpr unsigned SPIN_LIMIT = 1000000;    // ~1-2 s of polling (s_sleep + one L2 round trip each): only a grid that can never become resident gets there
 
 // Sticky per-device count of timed-out waits (besides the per-call sync[1] word): the host reads it with
 // laed_gru_persist_timeouts() whenever it next synchronises anyway (e.g. when it sees a NaN loss), so a poisoned output

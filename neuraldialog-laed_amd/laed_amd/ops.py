@@ -279,7 +279,16 @@ def linear(x, W, b=None):
     return LinearFunction.apply(x, W, b)
 
 
-_CU_SHARE = {"streams": 1}
+_CU_SHARE = {"streams": 1, "processes": 1}
+
+
+def set_device_sharers(n):
+    """Tell the engine that `n` processes run on THIS GPU (a rehearsal of the multi-rank path on fewer GPUs than
+    ranks; production is one process per GPU, n = 1).  The persistent small-batch GRU kernels need their whole grid
+    resident at once and cannot see another process's grid, so each process then only counts on 1/n of the CUs --
+    two 256-workgroup grids of two processes on one GPU would otherwise wait for each other until their bounded polls
+    give up (seconds per launch, NaN outputs)."""
+    _CU_SHARE["processes"] = max(1, int(n))
 
 
 class concurrent_streams(object):
@@ -302,7 +311,7 @@ class concurrent_streams(object):
 
 
 def _cu_budget(device):
-    n = _CU_SHARE["streams"]
+    n = _CU_SHARE["streams"] * _CU_SHARE["processes"]
     if n <= 1:
         return 0                                            # the whole device
     return max(1, torch.cuda.get_device_properties(device).multi_processor_count // n)
@@ -410,7 +419,8 @@ class LatentLossFunction(torch.autograd.Function):
         Bg = float(B)
         if group is not None:
             import torch.distributed as dist
-            dist.all_reduce(stats, group=group)
+            from . import parallel
+            parallel.all_reduce_(stats, group)
             Bg = float(B * dist.get_world_size(group))       # equal shards per rank
         scal = torch.empty(4, device=dev, dtype=torch.float32)
         coef = torch.empty(y_size * k, device=dev, dtype=torch.float32)
@@ -454,7 +464,8 @@ class AvgLogQyFunction(torch.autograd.Function):
         Bg = float(B)
         if group is not None:
             import torch.distributed as dist
-            dist.all_reduce(stats, group=group)
+            from . import parallel
+            parallel.all_reduce_(stats, group)
             Bg = float(B * dist.get_world_size(group))
         avg = torch.empty((y_size, k), device=dev, dtype=torch.float32)
         check(lib.laed_avg_log_fwd(ptr(stats), Bg, n, ptr(avg), stream()), "laed_avg_log_fwd")

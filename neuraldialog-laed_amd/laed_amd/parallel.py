@@ -31,6 +31,7 @@ def init(group=None):
 def shutdown():
     global _GROUP, _ENABLED
     _GROUP, _ENABLED = None, False
+    _GLOO.clear()
 
 
 def group():
@@ -46,9 +47,33 @@ def rank():
     return dist.get_rank(_GROUP) if _ENABLED else 0
 
 
+_GLOO = {}
+
+
+def _is_gloo(group):
+    if group not in _GLOO:
+        _GLOO[group] = str(dist.get_backend(group)).lower() == "gloo"
+    return _GLOO[group]
+
+
+def all_reduce_(t, group=None):
+    """In-place SUM all-reduce of `t` over `group` (default: the DP group) on the current stream.
+
+    Backend "nccl" (RCCL) is stream-ordered and needs nothing else.  Backend "gloo" is only the transport of the tests
+    and of bench.py's rehearsal mode (several ranks sharing one GPU); torch's gloo path for CUDA tensors never completes
+    on this ROCm stack when the collective is issued while the stream still has kernels in flight and another process
+    shares the GPU (tools/exp/gloo_shared_gpu.py reproduces it with plain torch matmuls; this was round 1's "4-rank
+    hang") -- so the stream is drained first."""
+    group = _GROUP if group is None else group
+    if t.is_cuda and _is_gloo(group):
+        torch.cuda.current_stream(t.device).synchronize()
+    dist.all_reduce(t, group=group)
+    return t
+
+
 def all_reduce_sum_(t):
     if _ENABLED:
-        dist.all_reduce(t, group=_GROUP)
+        all_reduce_(t)
     return t
 
 
@@ -111,9 +136,9 @@ class GradReducer(object):
                     self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 t.record_stream(self.stream)
-                dist.all_reduce(t, group=_GROUP)
+                all_reduce_(t)
         else:                                   # CPU / gloo test path
-            dist.all_reduce(t, group=_GROUP)
+            all_reduce_(t)
 
     def _flush(self):
         if not self._pending:
@@ -145,7 +170,7 @@ class GradReducer(object):
                 views.append((p, v))
                 off += k
             self.collectives += 1
-            dist.all_reduce(flat, group=_GROUP)
+            all_reduce_(flat)
         if side:
             flat.record_stream(torch.cuda.current_stream())
         for p, v in views:

@@ -42,6 +42,8 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
     else:
         dist.init_process_group("gloo", **rdzv)
     parallel.init()
+    from laed_amd import ops
+    ops.set_device_sharers(world)                  # the ranks share one GPU here (production: one process per GPU)
     G = load_golden(kind + "_mid")
     cfg = golden_config(G)
     cfg.use_gpu = True
