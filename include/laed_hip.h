@@ -145,7 +145,10 @@ int laed_gumbel_latent_bwd(const float* y, const float* dy, const float* log_qy,
  *                           workspace: nblk*(y*k+2) floats, nblk = laed_latent_stats_blocks()
  *  2. laed_latent_finalize: scal[0]=bpr, scal[1]=mi, scal[2]=row-KL mean (use_mutual=False reg_kl),
  *                           coef[y][k] = d bpr / d q[b][y][k]  (global batch size B_global)
- *  3. laed_latent_bwd:      dlog_qy[r][:] (+)= gscale[0] * (use_mutual ? coef.*q : row-KL term)
+ *  3. laed_latent_bwd:      dlog_qy[r][:] (+)= gscale[0] * (use_mutual == 1 ? coef.*q : use_mutual == 0 ? row-KL term
+ *                                                          : d mi / d log_qy with coef from laed_latent_mi_coef)
+ *     laed_latent_mi_coef:  coef[y][k] for the MI term (sent_models.py:155-156: mi is part of the returned Pack, so a
+ *                           caller may differentiate it although no valid_loss of the reference does)
  * ------------------------------------------------------------------------------------------ */
 int laed_latent_stats_blocks(void);
 int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats, void* stream);
@@ -158,6 +161,7 @@ int laed_latent_finalize(const float* stats, double B_global, int y, int k, floa
  * allocates (no hipMalloc / hipFree / torch).  Call it with the stream's device current.  All calls on one GPU share
  * the array: calls that overlap on one GPU (two streams) race -- serialise them. */
 int laed_latent_stats_noalloc(const float* log_qy, int64_t B, int y, int k, float* stats, void* stream);
+int laed_latent_mi_coef(const float* stats, double B_global, int y, int k, float* coef, void* stream);
 int laed_latent_bwd(const float* log_qy, const float* coef, const float* gscale, int use_mutual,
                     int64_t B, double B_global, int y, int k, float* dlog_qy, int accumulate, void* stream);
 
@@ -228,6 +232,10 @@ int laed_softmax_embed_bwd(const float* h, const float* W, const float* b, const
 /* log-probabilities for callers that really want the [N][V] tensor (DecoderRNN's public contract,
  * decoders.py:166): logp = logits - lse, in place on a caller buffer of [N][ldl]. */
 int laed_log_softmax_rows(float* logits, int64_t N, int V, int ldl, float* lse, void* stream);
+/* its backward, for a caller that builds a loss on the dense tensor: dlogits = dlogp - exp(logp) * rowsum(dlogp)
+ * (row strides in floats; dlogits may alias dlogp); dh / dW / db then follow from laed_sgemm as for any nn.Linear. */
+int laed_log_softmax_rows_bwd(const float* logp, int64_t ld_logp, const float* dlogp, int64_t ld_dlogp, int64_t N, int V,
+                              float* dlogits, int64_t ld_dlogits, void* stream);
 
 /* greedy symbol selection  ids[r] = argmax_v logits[r][v]  (lowest index on ties), decoders.py:218-219
  * (topk(1) of log_softmax == argmax of logits). */

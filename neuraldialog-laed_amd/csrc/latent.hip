@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
         const float lq = log_qy[i];
         const float q = expf(lq);
         float d;
-        if (use_mutual) d = g * coef[i % yk] * q;               // d bpr / d log_qy = coef * q
+        if (use_mutual == 2) d = g * q * (coef[i % yk] + (lq + 1.0f) / rows_g);      // d mi / d log_qy (coef from mi_coef)
+        else if (use_mutual) d = g * coef[i % yk] * q;          // d bpr / d log_qy = coef * q
         else d = g * q * ((lq - logu) + 1.0f) / rows_g;
         dlog_qy[i] = accumulate ? dlog_qy[i] + d : d;
     }
@@ -270,6 +271,17 @@ __global__ __launch_bounds__(256) void cat_rows_bwd_kernel(const float* __restri
         } else if (dlog_qy != nullptr) {
             dlog_qy[i] = -g * q * (lq + 1.0f);                                    // d/dlq  -lq q
         }
+    }
+}
+
+// MI = mean_y H(exp l) - mean_rows H(q_row), l = log(qbar + 1e-15) (sent_models.py:155-156, criterions.py:136-147):
+// coef[e] = d [mean_y H(exp l)] / d q[b][e] = -exp(l) (l + 1) / (qbar + 1e-15) / (y Bg); the per-row entropy term is added
+// by latent_bwd_kernel (mode 2).
+__global__ __launch_bounds__(256) void mi_coef_kernel(const float* __restrict__ stats, float Bg, int y, int n, float* __restrict__ coef) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const float qbar = stats[e] / Bg;
+        const float l = logf(qbar + 1e-15f);
+        coef[e] = -1.0f * expf(l) * (l + 1.0f) / (qbar + 1e-15f) / ((float)y * Bg);
     }
 }
 
@@ -436,6 +448,15 @@ extern "C" int laed_cat_rows_bwd(const float* log_qy, const float* log_py, int64
     hipLaunchKernelGGL(cat_rows_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, log_py, py_rows, py_cols, R, k,
                        gscale, scale, dlog_qy, dlog_py);
     LAED_LAUNCH_CHECK("cat_rows_bwd");
+    return 0;
+}
+
+extern "C" int laed_latent_mi_coef(const float* stats, double B_global, int y, int k, float* coef, void* stream) {
+    LAED_CHECK_ARG(B_global > 0 && y > 0 && k > 0, "latent_mi_coef: bad size");
+    LAED_CHECK_ARG(stats && coef, "latent_mi_coef: null pointer");
+    const int n = y * k;
+    hipLaunchKernelGGL(mi_coef_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (float)B_global, y, n, coef);
+    LAED_LAUNCH_CHECK("latent_mi_coef");
     return 0;
 }
 

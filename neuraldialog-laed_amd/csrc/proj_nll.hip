@@ -305,6 +305,28 @@ __global__ __launch_bounds__(256) void nll_gather_bwd_kernel(const int64_t* __re
     }
 }
 
+// Backward of log-softmax over rows, for callers that differentiate the DENSE log-prob tensor (DecoderRNN's public
+// contract, decoders.py:166): dlogits[r][v] = dlogp[r][v] - exp(logp[r][v]) * sum_v dlogp[r][v].  One block per row
+// (grid-stride), two passes; scalar accesses so that any row stride works.  dlogits may alias dlogp.
+__global__ __launch_bounds__(256) void log_softmax_rows_bwd_kernel(const float* __restrict__ logp, int64_t ldp, const float* dlogp,
+                                                                   int64_t ldd, int64_t rows, int V, float* dlogits, int64_t ldo) {
+    __shared__ float ss[4];
+    const int tid = threadIdx.x;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* d = dlogp + row * ldd;
+        const float* lp = logp + row * ldp;
+        float s = 0.f;
+        for (int i = tid; i < V; i += 256) s += d[i];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) ss[tid >> 6] = s;
+        __syncthreads();
+        const float tot = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+        float* o = dlogits + row * ldo;
+        for (int i = tid; i < V; i += 256) o[i] = d[i] - expf(lp[i]) * tot;
+        __syncthreads();
+    }
+}
+
 // dst[c][r] = src[r][c] for a [R][C] fp32 matrix (row stride ld), dst row stride ldd.  64x64 tiles through a
 // padded LDS tile, float4 (16-byte) accesses on both sides when alignment allows: HBM-bound.
 template <bool VEC>
@@ -473,6 +495,17 @@ extern "C" int laed_log_softmax_rows(float* logits, int64_t N, int V, int ldl, f
     if (N == 0) return 0;
     LAED_CHECK_ARG(logits && aligned16(logits), "log_softmax_rows: null or unaligned pointer");
     return launch_rows<MODE_LOGP>(logits, N, V, (int64_t)ldl, nullptr, nullptr, (int64_t)-1, nullptr, lse, (hipStream_t)stream);
+}
+
+extern "C" int laed_log_softmax_rows_bwd(const float* logp, int64_t ld_logp, const float* dlogp, int64_t ld_dlogp, int64_t N, int V,
+                                         float* dlogits, int64_t ld_dlogits, void* stream) {
+    LAED_CHECK_ARG(N >= 0 && V > 0 && ld_logp >= V && ld_dlogp >= V && ld_dlogits >= V, "log_softmax_rows_bwd: bad size");
+    if (N == 0) return 0;
+    LAED_CHECK_ARG(logp && dlogp && dlogits, "log_softmax_rows_bwd: null pointer");
+    hipLaunchKernelGGL(log_softmax_rows_bwd_kernel, dim3(rows_grid(N)), dim3(256), 0, (hipStream_t)stream, logp, ld_logp, dlogp,
+                       ld_dlogp, N, V, dlogits, ld_dlogits);
+    LAED_LAUNCH_CHECK("log_softmax_rows_bwd");
+    return 0;
 }
 
 extern "C" int laed_argmax_rows(const float* logits, int64_t N, int V, int ldl, int64_t* ids, void* stream) {

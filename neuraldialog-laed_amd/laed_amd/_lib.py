@@ -45,6 +45,7 @@ _SIGS = {
     "laed_latent_stats": ([_p, _i64, _i, _i, _p, _p, _p], _i),
     "laed_latent_stats_noalloc": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_latent_finalize": ([_p, _d, _i, _i, _p, _p, _p], _i),
+    "laed_latent_mi_coef": ([_p, _d, _i, _i, _p, _p], _i),
     "laed_latent_bwd": ([_p, _p, _p, _i, _i64, _d, _i, _i, _p, _i, _p], _i),
     "laed_avg_log_fwd": ([_p, _d, _i, _p, _p], _i),
     "laed_avg_log_coef": ([_p, _p, _d, _i, _p, _p], _i),
@@ -58,6 +59,7 @@ _SIGS = {
     "laed_softmax_embed_fwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _p, _i64, _i, _p, _p, _p], _i),
     "laed_softmax_embed_bwd": ([_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _i64, _i, _p, _p, _p, _p, _i, _p], _i),
     "laed_log_softmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
+    "laed_log_softmax_rows_bwd": ([_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p], _i),
     "laed_argmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_nll_reduce": ([_p, _p, _i64, _i64, _p, _p], _i),
     "laed_nll_gather_fwd": ([_p, _i64, _p, _i64, _i, _i64, _p, _p], _i),

@@ -112,4 +112,4 @@ class BatchPriorKL(_Loss):
             reg_kl = self.cat_kl_loss(avg_log_qy, ops.LogSoftmaxKFunction.apply(log_py), None, unit_average=True)
         else:
             reg_kl = b_pr
-        return reg_kl, b_pr, mi.detach()
+        return reg_kl, b_pr, mi

@@ -30,13 +30,21 @@ class LazyLogProbs(object):
         self._dense = None
 
     def materialize(self):
-        """Dense [B,T,V] log-probs (detached; gradients flow only through the fused NLL path)."""
-        if self._dense is None:
+        """Dense [B,T,V] log-probs.  With the tape on and anything upstream requiring grad the tensor is differentiable
+        (ops.DenseLogProbsFunction: a loss built on it reaches the decoder and the projection, as with the reference's
+        tensor); under no_grad it is plain data.  The fused NLL path never materialises."""
+        needs_tape = torch.is_grad_enabled() and (self.h_tm.requires_grad or self.project.weight.requires_grad)
+        if self._dense is not None and (self._dense.requires_grad or not needs_tape):
+            return self._dense
+        h_bf = self.h_tm.transpose(0, 1).reshape(self.B * self.T, -1)
+        if needs_tape:
+            dense = ops.DenseLogProbsFunction.apply(h_bf, self.project.weight, self.project.bias)
+        else:
             with torch.no_grad():
-                h_bf = self.h_tm.detach().transpose(0, 1).reshape(self.B * self.T, -1)
-                buf = ops.logits_rows(h_bf, self.project.weight.detach(), self.project.bias.detach())
+                buf = ops.logits_rows(h_bf.detach(), self.project.weight.detach(), self.project.bias.detach())
                 ops.log_softmax_rows_(buf, self.V)
-                self._dense = buf[:, :self.V].view(self.B, self.T, self.V)
+                dense = buf[:, :self.V]
+        self._dense = dense.view(self.B, self.T, self.V)
         return self._dense
 
     def expected_embedding_tm(self, emb_weight):

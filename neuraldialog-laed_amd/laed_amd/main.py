@@ -1,15 +1,23 @@
-"""Train / validate loop with the reference's control flow (mirror of laed/main.py:17-181).
+"""Training engine: the behaviour of laed/main.py:17-244 (the reference's train / validate / generate and LossManager),
+written against that behaviour rather than its text.
 
-Same step order (zero_grad -> forward(TEACH_FORCE) -> [flush_valid] -> backward -> step), ckpt_step pseudo-epochs,
-patience rule, best-valid checkpoint (`torch.save(model.state_dict())`, reference-compatible keys) and LossManager
-windows/PPL.  Differences: loss scalars stay on the device until a print / checkpoint step reads them (the reference's
-per-step `val.data[0]` is a device synchronisation per loss term and no longer runs on 0-dim tensors anyway),
-validation runs under torch.no_grad().  `get_sent` / `generate` (laed/main.py:52-78,184-243) turn greedy / sampled id
-matrices back into text for the `gen` callback and the BLEU evaluator.
+What is kept, because callers and checkpoints depend on it:
+  * the step order  zero_grad -> forward(TEACH_FORCE) -> [flush_valid: forget the best loss, rebuild the optimizer]
+    -> backward -> optimizer.step  (laed/main.py:104-113);
+  * a "pseudo-epoch" every `config.ckpt_step` batches: validate, preview generation, then the patience rule
+    (laed/main.py:123-158): a new best validation loss is saved; one that also beats `improve_threshold` x the last
+    significant best stretches patience to max(patience, epochs_done x patient_increase); training ends at `max_epoch`
+    pseudo-epochs or, with `early_stop`, once patience <= epochs_done;
+  * the checkpoint is `torch.save(model.state_dict(), <session_dir>/model)` with the reference's key names;
+  * LossManager's interface (add_loss / add_backward_loss / clear / pprint / avg_loss) and PPL = exp(mean) for every
+    key that contains "nll" (laed/main.py:17-49).
+What differs: loss scalars stay on the device until a report reads them (the reference synchronises per loss term per
+step with `val.data[0]`, which no longer runs on 0-dim tensors), validation runs under `torch.no_grad()`, and the
+patience bookkeeping lives in `EarlyStopping`, which `tests/test_host_logic_cpu.py` drives through scripted
+validation losses without a GPU.
 """
 import logging
 import os
-from collections import defaultdict
 
 import numpy as np
 import torch
@@ -22,228 +30,288 @@ from .utils import get_dekenize
 logger = logging.getLogger()
 
 
-class _LazyScalars(list):
-    """List of loss scalars that keeps device tensors as they are appended and copies them to the host in ONE transfer
-    when somebody reads the list.  The reference reads every loss term with `val.data[0]` per step (main.py:25), i.e.
-    several device synchronisations per step; here the train loop never waits for the GPU between print steps."""
+# ----------------------------------------------------------------------------------------------------------------
+# loss bookkeeping
+# ----------------------------------------------------------------------------------------------------------------
+class _Series(object):
+    """Scalars in arrival order.  Device tensors are parked as they come and fetched in ONE device->host copy when the
+    series is read, so the step loop never waits for the GPU between reports."""
 
     def __init__(self):
-        super(_LazyScalars, self).__init__()
-        self._pending = []
+        self._host = []
+        self._parked = []
 
-    def append(self, val):
-        if torch.is_tensor(val):
-            self._pending.append(val.detach().reshape(1))
+    def push(self, value):
+        if torch.is_tensor(value):
+            self._parked.append(value.detach().reshape(1))
         else:
-            self._flush()
-            super(_LazyScalars, self).append(float(val))
+            self.values()                       # keep arrival order
+            self._host.append(float(value))
 
-    def _flush(self):
-        if self._pending:
-            vals, self._pending = self._pending, []
-            super(_LazyScalars, self).extend(torch.cat(vals).float().cpu().tolist())
+    def values(self):
+        if self._parked:
+            parked, self._parked = self._parked, []
+            self._host.extend(torch.cat(parked).float().cpu().tolist())
+        return self._host
 
+    def mean(self, last=None):
+        v = self.values()
+        return float(np.mean(v if last is None else v[-last:]))
+
+    # list protocol, for callers that index / iterate `manager.losses[key]` as the reference's plain lists
     def __len__(self):
-        self._flush()
-        return super(_LazyScalars, self).__len__()
+        return len(self.values())
 
     def __iter__(self):
-        self._flush()
-        return super(_LazyScalars, self).__iter__()
+        return iter(self.values())
 
     def __getitem__(self, i):
-        self._flush()
-        return super(_LazyScalars, self).__getitem__(i)
+        return self.values()[i]
 
 
 class LossManager(object):
+    """Per-key running record of the 0-dim loss terms of a Pack plus the scalar that drives model selection."""
+
     def __init__(self):
-        self.losses = defaultdict(_LazyScalars)
-        self.backward_losses = _LazyScalars()
+        self.clear()
+
+    def clear(self):
+        self.losses = {}
+        self.backward_losses = _Series()
 
     def add_loss(self, loss):
         for key, val in loss.items():
-            if val is not None and type(val) is not bool and torch.is_tensor(val) and val.dim() == 0:
-                self.losses[key].append(val)
+            if torch.is_tensor(val) and val.dim() == 0:     # skips None, flags and per-row tensors
+                self.losses.setdefault(key, _Series()).push(val)
 
     def add_backward_loss(self, loss):
-        self.backward_losses.append(loss)
-
-    def clear(self):
-        self.losses = defaultdict(_LazyScalars)
-        self.backward_losses = _LazyScalars()
-
-    def pprint(self, name, window=None, prefix=None):
-        str_losses = []
-        for key, loss in self.losses.items():
-            if loss is None:
-                continue
-            loss = list(loss)
-            avg_loss = np.average(loss) if window is None else np.average(loss[-window:])
-            str_losses.append("{} {:.3f}".format(key, avg_loss))
-            if 'nll' in key:
-                str_losses.append("PPL {:.3f}".format(np.exp(avg_loss)))
-        if prefix:
-            return "{}: {} {}".format(prefix, name, " ".join(str_losses))
-        return "{} {}".format(name, " ".join(str_losses))
+        self.backward_losses.push(loss)
 
     def avg_loss(self):
-        return np.mean(list(self.backward_losses))
+        return self.backward_losses.mean()
+
+    def pprint(self, name, window=None, prefix=None):
+        cells = []
+        for key, series in self.losses.items():
+            m = series.mean(window)
+            cells.append("%s %.3f" % (key, m))
+            if 'nll' in key:
+                cells.append("PPL %.3f" % np.exp(m))
+        head = name if not prefix else "%s: %s" % (prefix, name)
+        return " ".join([head] + cells)
+
+
+class EarlyStopping(object):
+    """The patience rule of laed/main.py:86-88,133-158 as a state object.
+
+    observe(valid_loss) is called once per pseudo-epoch and returns (is_new_best, patience_was_extended); finished()
+    then says whether training ends.  flush() is the `flush_valid` reset (laed/main.py:106-110): only the best loss is
+    forgotten -- the significance threshold and the patience already earned stay."""
+
+    def __init__(self, max_epoch, early_stop, improve_threshold, patient_increase, initial_patience=10):
+        self.max_epoch = max_epoch
+        self.early_stop = early_stop
+        self.improve_threshold = improve_threshold
+        self.patient_increase = patient_increase
+        self.patience = initial_patience
+        self.epochs_done = 0
+        self.best = np.inf
+        self.significant_best = np.inf
+
+    def flush(self):
+        self.best = np.inf
+
+    def observe(self, valid_loss):
+        self.epochs_done += 1
+        if not valid_loss < self.best:
+            return False, False
+        extended = False
+        if valid_loss <= self.significant_best * self.improve_threshold:
+            self.patience = max(self.patience, self.epochs_done * self.patient_increase)
+            self.significant_best = valid_loss
+            extended = True
+        self.best = valid_loss
+        return True, extended
+
+    def out_of_patience(self):
+        return bool(self.early_stop) and self.patience <= self.epochs_done
+
+    def finished(self):
+        return self.epochs_done >= self.max_epoch or self.out_of_patience()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# train / validate
+# ----------------------------------------------------------------------------------------------------------------
+def _batches(feed):
+    while True:
+        batch = feed.next_batch()
+        if batch is None:
+            return
+        yield batch
+
+
+def _save_checkpoint(model, config):
+    path = os.path.join(config.session_dir, "model")
+    torch.save(model.state_dict(), path)
+    return path
 
 
 def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=None):
-    """laed/main.py:81-162.  Returns the best validation loss."""
-    patience = 10
-    valid_loss_threshold = np.inf
-    best_valid_loss = np.inf
-    batch_cnt = 0
+    """Train until `max_epoch` pseudo-epochs or the patience rule stops it; returns the best validation loss.
+
+    `gen(model, test_feed, config, evaluator, num_batch=...)` previews generations at every pseudo-epoch.  As in the
+    reference (laed/main.py:82-83) it defaults to `generate` -- when there is an evaluator to hand to it; with neither,
+    the preview is skipped."""
+    if gen is None and evaluator is not None:
+        gen = generate
+    stopper = EarlyStopping(config.max_epoch, config.early_stop, config.improve_threshold, config.patient_increase)
     optimizer = model.get_optimizer(config)
-    done_epoch = 0
-    train_loss = LossManager()
+    seen = LossManager()
+    step_no = 0
     model.train()
     logger.info(summary(model, show_weights=False))
-    logger.info("**** Training Begins ****")
-    logger.info("**** Epoch 0/{} ****".format(config.max_epoch))
+    logger.info("Training starts: up to %d pseudo-epochs of %d batches", config.max_epoch, config.ckpt_step)
     while True:
-        train_feed.epoch_init(config, verbose=done_epoch == 0, shuffle=True)
-        while True:
-            batch = train_feed.next_batch()
-            if batch is None:
-                break
+        train_feed.epoch_init(config, verbose=stopper.epochs_done == 0, shuffle=True)
+        for batch in _batches(train_feed):
             optimizer.zero_grad()
             loss = model(batch, mode=TEACH_FORCE)
-            if model.flush_valid:
-                logger.info("Flush previous valid loss")
-                best_valid_loss = np.inf
+            if model.flush_valid:               # the model switched training phase inside this forward
+                logger.info("Training phase changed: forgetting the best validation loss, new optimizer")
+                stopper.flush()
                 model.flush_valid = False
                 optimizer = model.get_optimizer(config)
-            model.backward(batch_cnt, loss)
+            model.backward(step_no, loss)
             optimizer.step()
-            batch_cnt += 1
-            train_loss.add_loss(loss)
-            if batch_cnt % config.print_step == 0:
-                logger.info(train_loss.pprint("Train", window=config.print_step,
-                                              prefix="{}/{}-({:.3f})".format(batch_cnt % config.ckpt_step,
-                                                                             config.ckpt_step, model.kl_w)))
-            if batch_cnt % config.ckpt_step == 0:
-                logger.info("\n=== Evaluating Model ===")
-                logger.info(train_loss.pprint("Train"))
-                done_epoch += 1
-                valid_loss = validate(model, valid_feed, config, batch_cnt)
-                if gen is not None:
-                    gen(model, test_feed, config, evaluator, num_batch=getattr(config, 'preview_batch_num', 1))
-                if valid_loss < best_valid_loss:
-                    if valid_loss <= valid_loss_threshold * config.improve_threshold:
-                        patience = max(patience, done_epoch * config.patient_increase)
-                        valid_loss_threshold = valid_loss
-                        logger.info("Update patience to {}".format(patience))
-                    if config.save_model:
-                        logger.info("Model Saved.")
-                        torch.save(model.state_dict(), os.path.join(config.session_dir, "model"))
-                    best_valid_loss = valid_loss
-                if done_epoch >= config.max_epoch or (config.early_stop and patience <= done_epoch):
-                    if done_epoch < config.max_epoch:
-                        logger.info("!!Early stop due to run out of patience!!")
-                    logger.info("Best validation loss %f" % best_valid_loss)
-                    return best_valid_loss
-                model.train()
-                train_loss.clear()
-                logger.info("\n**** Epcoch {}/{} ****".format(done_epoch, config.max_epoch))
+            step_no += 1
+            seen.add_loss(loss)
+
+            if step_no % config.print_step == 0:
+                where = "%d/%d-(%.3f)" % (step_no % config.ckpt_step, config.ckpt_step, model.kl_w)
+                logger.info(seen.pprint("Train", window=config.print_step, prefix=where))
+            if step_no % config.ckpt_step != 0:
+                continue
+
+            # ---- pseudo-epoch boundary
+            logger.info("Pseudo-epoch %d done; %s", stopper.epochs_done + 1, seen.pprint("Train"))
+            valid_loss = validate(model, valid_feed, config, step_no)
+            if gen is not None:
+                gen(model, test_feed, config, evaluator, num_batch=getattr(config, 'preview_batch_num', 1))
+            is_best, extended = stopper.observe(valid_loss)
+            if extended:
+                logger.info("Significant improvement: patience is now %s pseudo-epochs", stopper.patience)
+            if is_best and config.save_model:
+                logger.info("New best validation loss %f, saved to %s", valid_loss, _save_checkpoint(model, config))
+            if stopper.finished():
+                if stopper.epochs_done < config.max_epoch:
+                    logger.info("Stopping early: patience %s used up after %d pseudo-epochs", stopper.patience,
+                                stopper.epochs_done)
+                logger.info("Best validation loss %f", stopper.best)
+                return stopper.best
+            model.train()
+            seen.clear()
+            logger.info("Pseudo-epoch %d/%d starts", stopper.epochs_done, config.max_epoch)
 
 
 def validate(model, valid_feed, config, batch_cnt=None):
-    """laed/main.py:165-181 (noise is still drawn in eval mode, as in the reference)."""
+    """Mean model-selection loss over one pass of `valid_feed` in eval mode (laed/main.py:165-181).  The Gumbel noise
+    is still drawn in eval mode, as in the reference; no tape is built."""
     model.eval()
     valid_feed.epoch_init(config, shuffle=False, verbose=True)
-    losses = LossManager()
+    seen = LossManager()
     with torch.no_grad():
-        while True:
-            batch = valid_feed.next_batch()
-            if batch is None:
-                break
+        for batch in _batches(valid_feed):
             loss = model(batch, mode=TEACH_FORCE)
-            losses.add_loss(loss)
-            losses.add_backward_loss(model.model_sel_loss(loss, batch_cnt))
-    valid_loss = losses.avg_loss()
-    logger.info(losses.pprint(valid_feed.name))
-    logger.info("Total valid loss {}".format(valid_loss))
+            seen.add_loss(loss)
+            seen.add_backward_loss(model.model_sel_loss(loss, batch_cnt))
+    valid_loss = seen.avg_loss()
+    logger.info("%s; selection loss %f", seen.pprint(valid_feed.name), valid_loss)
     return valid_loss
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# ids -> text, preview generation
+# ----------------------------------------------------------------------------------------------------------------
 def get_sent(model, de_tknize, data, b_id, attn=None, attn_ctx=None, stop_eos=True, stop_pad=True):
-    """Row b_id of an id matrix as text (laed/main.py:52-78): stops at </s> / </t> (keeping </t>) and at PAD; with
-    attention scores, also lists the context words that got more than 0.1 of the mass."""
-    words, attn_words = [], []
-    has_attn = attn is not None and attn_ctx is not None
-    for t_id in range(data.shape[1]):
-        w = model.vocab[int(data[b_id, t_id])]
-        if has_attn:
-            a_val = np.max(attn[b_id, t_id])
-            if a_val > 0.1:
-                attn_words.append("{}({})".format(model.vocab[int(attn_ctx[b_id, np.argmax(attn[b_id, t_id])])], a_val))
-        if (stop_eos and w in (EOS, EOT)) or (stop_pad and w == PAD):
-            if w == EOT:
-                words.append(w)
+    """(text, attention note) for row `b_id` of an id matrix (laed/main.py:52-78).  Reading stops at the first </s> or
+    </t> (a </t> is kept in the text) when `stop_eos`, and at the first PAD when `stop_pad`; PAD is never printed.  With
+    attention scores [B,T,C] and the attended ids, context words holding more than 0.1 of a step's mass are listed."""
+    row = data[b_id]
+    with_attn = attn is not None and attn_ctx is not None
+    words, noted = [], []
+    for t_id in range(len(row)):
+        word = model.vocab[int(row[t_id])]
+        if with_attn:
+            weight = float(np.max(attn[b_id, t_id]))
+            if weight > 0.1:
+                src = model.vocab[int(attn_ctx[b_id, int(np.argmax(attn[b_id, t_id]))])]
+                noted.append("%s(%s)" % (src, weight))
+        ends_turn = stop_eos and word in (EOS, EOT)
+        if ends_turn or (stop_pad and word == PAD):
+            if word == EOT:
+                words.append(word)
             break
-        if w != PAD:
-            words.append(w)
-    att = "Attention: {}".format(" ".join(attn_words)) if attn_words else ""
+        if word != PAD:
+            words.append(word)
+    note = "Attention: " + " ".join(noted) if (with_attn and noted) else ""
     try:
-        return de_tknize(words), att if has_attn else ""
-    except Exception:                       # a detokeniser that rejects the tokens: plain join, as the reference
+        return de_tknize(words), note
+    except Exception:                           # a detokeniser that rejects the tokens: plain join, no note
         return " ".join(words), ""
 
 
 def sequences_of(ret_dict):
-    """[B, max_len] int matrix of generated ids from a decoder's ret_dict (list of [B,1] id tensors per step)."""
-    seq = ret_dict[DecoderRNN.KEY_SEQUENCE]
-    if len(seq) == 0:
+    """[B, max_len] int matrix of generated ids from a decoder's ret_dict (a list of [B,1] id tensors per step): one
+    device->host copy per batch instead of one per step."""
+    steps = ret_dict[DecoderRNN.KEY_SEQUENCE]
+    if not steps:
         return np.zeros((0, 0), dtype=int)
-    return torch.cat([t.reshape(-1, 1) for t in seq], dim=1).cpu().numpy().astype(int)      # one device->host copy
+    return torch.cat([s.reshape(-1, 1) for s in steps], dim=1).cpu().numpy().astype(int)
+
+
+def _attention_of(ret_dict, config):
+    """[B,T,C] attention scores if the decoder produced any (never with the scripts' defaults: use_attn=False)."""
+    wants = getattr(config, 'use_attn', False) or getattr(config, 'use_ptr', False)
+    if not wants or DecoderRNN.KEY_ATTN_SCORE not in ret_dict:
+        return None
+    per_step = [a.cpu().numpy() for a in ret_dict[DecoderRNN.KEY_ATTN_SCORE]]
+    return np.array(per_step, dtype=float).squeeze(2).swapaxes(0, 1)
 
 
 def generate(model, data_feed, config, evaluator, num_batch=1, dest_f=None):
-    """Response generation over a dialog feed with per-domain BLEU (laed/main.py:184-243)."""
+    """Free-running generation over `data_feed` (all of it when `num_batch` is None), every (reference, hypothesis)
+    pair handed to `evaluator` under its dialog domain, the evaluator's report at the end (laed/main.py:184-243).
+    Lines go to `dest_f` if given, else to the log; single examples are only printed for short previews."""
     model.eval()
     de_tknize = get_dekenize()
-
-    def write(msg):
-        if msg is None or msg == '':
-            return
-        if dest_f is None:
-            logger.info(msg)
-        else:
-            dest_f.write(msg + '\n')
-
+    emit = (lambda line: dest_f.write(line + '\n')) if dest_f is not None else logger.info
+    verbose = num_batch is None or num_batch <= 2
     data_feed.epoch_init(config, shuffle=num_batch is not None, verbose=False)
     evaluator.initialize()
-    logger.info("Generation: {} batches".format(data_feed.num_batch if num_batch is None else num_batch))
-    while True:
-        batch = data_feed.next_batch()
-        if batch is None or (num_batch is not None and data_feed.ptr > num_batch):
+    logger.info("Generating over %s batches", data_feed.num_batch if num_batch is None else num_batch)
+    for batch in _batches(data_feed):
+        if num_batch is not None and data_feed.ptr > num_batch:
             break
         with torch.no_grad():
             outputs, labels = model(batch, mode=GEN, gen_type=config.gen_type)
-        pred_labels = sequences_of(outputs)
-        true_labels = labels.cpu().numpy()
-        pred_attns = None
-        if (getattr(config, 'use_attn', False) or getattr(config, 'use_ptr', False)) and DecoderRNN.KEY_ATTN_SCORE in outputs:
-            pred_attns = np.array([t.cpu().numpy() for t in outputs[DecoderRNN.KEY_ATTN_SCORE]], dtype=float).squeeze(2).swapaxes(0, 1)
-        ctx, ctx_len = batch.get('contexts'), batch.get('context_lens')
-        domains = batch.get('domains')
-        for b_id in range(pred_labels.shape[0]):
-            pred_str, attn = get_sent(model, de_tknize, pred_labels, b_id, attn=pred_attns)
-            true_str, _ = get_sent(model, de_tknize, true_labels, b_id)
-            prev_ctx = ""
-            if ctx is not None:
-                ctx_str, _ = get_sent(model, de_tknize, ctx[:, ctx_len[b_id] - 1, :], b_id)
-                prev_ctx = "Source: {}".format(ctx_str)
-            domain = domains[b_id] if domains is not None else 'default'
-            evaluator.add_example(true_str, pred_str, domain)
-            if num_batch is None or num_batch <= 2:
-                write(prev_ctx)
-                write("{}:: True: {} ||| Pred: {}".format(domain, true_str, pred_str))
-                if attn:
-                    write("[[{}]]".format(attn))
-    write(evaluator.get_report(include_error=dest_f is not None))
-    logger.info("Generation Done")
+        hyp_ids, ref_ids = sequences_of(outputs), labels.cpu().numpy()
+        scores = _attention_of(outputs, config)
+        contexts, context_lens, domains = batch.get('contexts'), batch.get('context_lens'), batch.get('domains')
+        for b_id in range(hyp_ids.shape[0]):
+            hyp, note = get_sent(model, de_tknize, hyp_ids, b_id, attn=scores)
+            ref, _ = get_sent(model, de_tknize, ref_ids, b_id)
+            domain = 'default' if domains is None else domains[b_id]
+            evaluator.add_example(ref, hyp, domain)
+            if not verbose:
+                continue
+            if contexts is not None:            # the turn right before the response
+                last_turn, _ = get_sent(model, de_tknize, contexts[:, context_lens[b_id] - 1, :], b_id)
+                emit("Source: " + last_turn)
+            emit("%s:: True: %s ||| Pred: %s" % (domain, ref, hyp))
+            if note:
+                emit("[[%s]]" % note)
+    report = evaluator.get_report(include_error=dest_f is not None)
+    if report:
+        emit(report)
+    logger.info("Generation done")

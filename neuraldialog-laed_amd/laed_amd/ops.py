@@ -165,6 +165,39 @@ def log_softmax_rows_(buf, V):
     return buf
 
 
+class DenseLogProbsFunction(torch.autograd.Function):
+    """h[N,H], W[V,H], b[V] -> log_softmax(h W^T + b) as a dense [N,V] tensor (a view of an [N,ldl] buffer), WITH a
+    backward: the reference's DecoderRNN returns this tensor (decoders.py:165-166) and a caller may build any loss on
+    it.  The fused NLL path never goes through here; this is the contract-keeping slow road (the [N,V] tensor and its
+    gradient are materialised)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        h = _f32c(h)
+        V = W.shape[0]
+        buf = logits_rows(h, W, b)
+        log_softmax_rows_(buf, V)
+        ctx.save_for_backward(h, W, buf)
+        ctx.has_bias = b is not None
+        return buf[:, :V]
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        h, W, buf = ctx.saved_tensors
+        N, V = h.shape[0], W.shape[0]
+        if dlogp.dtype != torch.float32 or dlogp.stride(1) != 1:
+            dlogp = dlogp.float().contiguous()
+        dl = torch.empty((N, V), device=h.device, dtype=torch.float32)
+        check(lib.laed_log_softmax_rows_bwd(ctypes_ptr(buf), buf.stride(0), ctypes_ptr(dlogp), dlogp.stride(0) if N > 1 else V,
+                                            N, V, ptr(dl), V, stream()), "laed_log_softmax_rows_bwd")
+        dh = sgemm(dl, W) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            db = torch.empty(V, device=h.device, dtype=torch.float32) if ctx.has_bias else None
+            dW = sgemm(dl, h, transA=True, colsum_out=db)
+        return dh, dW, db
+
+
 def decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, proj_w, proj_b, h0, max_len, go_id, sample=False, u=None, seed=0,
                   row0=0):
     """Free-running decode from h0 [B,H]: greedy, or (sample=True) Gumbel-max sampling with replayed uniforms
@@ -425,24 +458,30 @@ class LatentLossFunction(torch.autograd.Function):
         scal = torch.empty(4, device=dev, dtype=torch.float32)
         coef = torch.empty(y_size * k, device=dev, dtype=torch.float32)
         check(lib.laed_latent_finalize(ptr(stats), Bg, y_size, k, ptr(scal), ptr(coef), stream()), "laed_latent_finalize")
-        ctx.save_for_backward(log_qy, coef)
+        ctx.save_for_backward(log_qy, coef, stats)
         ctx.meta = (B, Bg, y_size, k)
+        ctx.set_materialize_grads(False)          # unused outputs (mi, row-KL in the default model) arrive as None
         return scal[0], scal[1], scal[2]
 
     @staticmethod
     def backward(ctx, d_bpr, d_mi, d_rowkl):
-        # mi is a logged quantity only (sent_models.py:155-158): no gradient path is provided for it.
-        log_qy, coef = ctx.saved_tensors
+        # mi is only logged by the reference's models (sent_models.py:155-158), but it is an ordinary differentiable
+        # member of the returned Pack there, so its gradient is provided too
+        log_qy, coef, stats = ctx.saved_tensors
         B, Bg, y_size, k = ctx.meta
         dlq = None
-        for g, mutual in ((d_bpr, 1), (d_rowkl, 0)):
+        for g, mode in ((d_bpr, 1), (d_rowkl, 0), (d_mi, 2)):
             if g is None:
                 continue
             g = _f32c(g).reshape(1)
             first = dlq is None
             if first:
                 dlq = torch.empty_like(log_qy)
-            check(lib.laed_latent_bwd(ptr(log_qy), ptr(coef), ptr(g), mutual, B, Bg, y_size, k, ptr(dlq), int(not first),
+            c = coef
+            if mode == 2:
+                c = torch.empty_like(coef)
+                check(lib.laed_latent_mi_coef(ptr(stats), Bg, y_size, k, ptr(c), stream()), "laed_latent_mi_coef")
+            check(lib.laed_latent_bwd(ptr(log_qy), ptr(c), ptr(g), mode, B, Bg, y_size, k, ptr(dlq), int(not first),
                                       stream()), "laed_latent_bwd")
         return dlq, None, None, None
 

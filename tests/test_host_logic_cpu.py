@@ -1,4 +1,6 @@
 """CPU-only tests of the host-side mirror of the reference API (no kernels are launched)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -222,3 +224,160 @@ def test_corpus_bleu_known_answers_and_tokenizers():
     assert get_tokenize()("hello <s> #tag %x, isn't it?") == ['hello', '<s>', '#tag', '%x', ',', 'isn', "'", 't', 'it', '?']
     assert get_chat_tokenize()("ok <sil> fine!") == ['ok', '<sil>', 'fine', '!']
     assert get_dekenize()(['i', 'do', "n't", 'know', ',', 'it', "'s", '(', 'ok', ')', '.']) == "i don't know, it's (ok)."
+
+
+# ---- engine control flow (laed/main.py:81-181) on a stub model: no GPU, scripted validation losses --------------------
+class _ScriptedModel(object):
+    """Counts what the engine calls, in order; `validate` sees the scripted losses one per pseudo-epoch."""
+    vocab = ['<pad>']
+    kl_w = 0.0
+
+    def __init__(self, valid_losses, flush_at=None):
+        self.valid_losses = list(valid_losses)
+        self.flush_at = flush_at
+        self.flush_valid = False
+        self.calls = []
+        self.training = True
+        self.optimizers = 0
+        self.saved = []
+        self._modules = {}
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def get_optimizer(self, config):
+        self.optimizers += 1
+        model = self
+
+        class Opt(object):
+            def zero_grad(self):
+                model.calls.append("zero_grad")
+
+            def step(self):
+                model.calls.append("step")
+        return Opt()
+
+    def __call__(self, batch, mode=None):
+        import torch
+        if self.training:
+            self.calls.append("forward")
+            if self.flush_at is not None and self.calls.count("forward") == self.flush_at:
+                self.flush_valid = True
+            return {"nll": torch.tensor(1.0)}
+        return {"nll": torch.tensor(float(self.valid_losses[0]))}
+
+    def backward(self, batch_cnt, loss):
+        self.calls.append("backward")
+
+    def model_sel_loss(self, loss, batch_cnt):
+        return loss["nll"]
+
+    def state_dict(self):
+        return {"epoch_marker": len(self.saved)}
+
+
+class _OneBatchFeed(object):
+    def __init__(self, name, n, model=None):
+        self.name, self.n, self.model, self.ptr, self.num_batch = name, n, model, 0, n
+
+    def epoch_init(self, config, shuffle=True, verbose=True):
+        self.ptr = 0
+
+    def next_batch(self):
+        if self.ptr >= self.n:
+            if self.model is not None and self.name == "Valid":
+                self.model.valid_losses.pop(0)          # one scripted loss per validation pass
+            return None
+        self.ptr += 1
+        return {"outputs": None}
+
+
+def _engine_cfg(tmp_path, **kw):
+    from argparse import Namespace
+    cfg = dict(print_step=1000, ckpt_step=2, max_epoch=50, early_stop=True, improve_threshold=0.996,
+               patient_increase=2.0, save_model=True, session_dir=str(tmp_path), preview_batch_num=1)
+    cfg.update(kw)
+    return Namespace(**cfg)
+
+
+def test_engine_step_order_patience_and_checkpoints(tmp_path, monkeypatch):
+    """The reference's control flow (laed/main.py:81-162) without a GPU: per step zero_grad -> forward -> backward ->
+    step; a checkpoint at every new best validation loss; patience 10 grows to max(patience, epochs x patient_increase)
+    only on an improvement beyond improve_threshold; training stops once patience <= epochs done."""
+    import torch
+    from laed_amd import main as engine
+    saves = []
+    monkeypatch.setattr(torch, "save", lambda sd, path: saves.append(path))
+    monkeypatch.setattr(engine, "summary", lambda *a, **k: "stub")
+    # epochs 1-6 improve (patience -> 12 at epoch 6), then nothing improves: stop when 12 <= epochs done
+    script = [5.0, 4.0, 3.0, 2.0, 1.5, 1.0] + [1.2] * 40
+    model = _ScriptedModel(script)
+    best = engine.train(model, _OneBatchFeed("Train", 2), _OneBatchFeed("Valid", 1, model), None, _engine_cfg(tmp_path))
+    assert best == 1.0
+    assert len(saves) == 6 and all(p == os.path.join(str(tmp_path), "model") for p in saves)
+    steps = model.calls
+    assert steps[:4] == ["zero_grad", "forward", "backward", "step"] and len(steps) % 4 == 0
+    assert all(steps[i:i + 4] == steps[:4] for i in range(0, len(steps), 4))
+    assert len(steps) // 4 == 12 * 2                                   # 12 pseudo-epochs of ckpt_step = 2 batches
+    # an improvement that is NOT significant (> 0.996 x the last significant best) is saved but earns no patience
+    es = engine.EarlyStopping(max_epoch=100, early_stop=True, improve_threshold=0.996, patient_increase=2.0)
+    assert es.observe(10.0) == (True, True) and es.patience == 10
+    for _ in range(5):
+        es.observe(11.0)
+    assert es.observe(9.99) == (True, False) and es.patience == 10 and es.best == 9.99 and es.significant_best == 10.0
+    assert es.observe(9.0) == (True, True) and es.patience == 16 and es.significant_best == 9.0      # epoch 8 x 2.0
+    assert not es.finished()
+    # max_epoch ends training whatever the patience; early_stop=False ignores patience
+    model = _ScriptedModel([3.0, 2.0, 1.0, 0.5])
+    best = engine.train(model, _OneBatchFeed("Train", 2), _OneBatchFeed("Valid", 1, model), None,
+                        _engine_cfg(tmp_path, max_epoch=3))
+    assert best == 1.0 and model.calls.count("step") == 6
+    es = engine.EarlyStopping(max_epoch=30, early_stop=False, improve_threshold=0.996, patient_increase=2.0)
+    for _ in range(20):
+        es.observe(1.0)
+    assert not es.finished()
+
+
+def test_engine_flush_valid_rebuilds_the_optimizer_and_forgets_the_best(tmp_path, monkeypatch):
+    """laed/main.py:106-110: when a forward raises model.flush_valid (AE-ED / ST-ED at freeze_step) the engine forgets
+    the best validation loss -- a worse loss after the switch is a new best and is saved -- clears the flag and asks
+    the model for a new optimizer BEFORE that step's backward."""
+    import torch
+    from laed_amd import main as engine
+    saves = []
+    monkeypatch.setattr(torch, "save", lambda sd, path: saves.append(path))
+    monkeypatch.setattr(engine, "summary", lambda *a, **k: "stub")
+    model = _ScriptedModel([1.0, 5.0, 4.0], flush_at=3)                # third training forward = first of pseudo-epoch 2
+    best = engine.train(model, _OneBatchFeed("Train", 2), _OneBatchFeed("Valid", 1, model), None,
+                        _engine_cfg(tmp_path, max_epoch=3))
+    assert model.optimizers == 2 and model.flush_valid is False
+    assert best == 4.0 and len(saves) == 3                             # 1.0, then (after the flush) 5.0 and 4.0
+    assert model.calls[8:12] == ["zero_grad", "forward", "backward", "step"]
+
+
+def test_engine_preview_generation_defaults_to_generate_with_an_evaluator(tmp_path, monkeypatch):
+    """laed/main.py:82-83,132: `gen` defaults to `generate` and runs at every pseudo-epoch; here the default applies when
+    an evaluator is passed (without one there is nothing to hand to it and the preview is skipped)."""
+    import torch
+    from laed_amd import main as engine
+    monkeypatch.setattr(torch, "save", lambda sd, path: None)
+    monkeypatch.setattr(engine, "summary", lambda *a, **k: "stub")
+    seen = []
+    monkeypatch.setattr(engine, "generate", lambda model, feed, config, evaluator, num_batch=1: seen.append((evaluator, num_batch)))
+    model = _ScriptedModel([2.0, 1.0])
+    engine.train(model, _OneBatchFeed("Train", 2), _OneBatchFeed("Valid", 1, model), "test-feed",
+                 _engine_cfg(tmp_path, max_epoch=2), evaluator="EV")
+    assert seen == [("EV", 1), ("EV", 1)]
+    seen[:] = []
+    model = _ScriptedModel([2.0, 1.0])
+    engine.train(model, _OneBatchFeed("Train", 2), _OneBatchFeed("Valid", 1, model), None, _engine_cfg(tmp_path, max_epoch=2))
+    assert seen == []
+    lm = engine.LossManager()
+    lm.add_loss({"nll": torch.tensor(2.0), "flag": True, "none": None, "rows": torch.zeros(3)})
+    lm.add_loss({"nll": torch.tensor(4.0)})
+    assert lm.pprint("x") == "x nll 3.000 PPL %.3f" % np.exp(3.0)
+    assert lm.pprint("x", window=1, prefix="p") == "p: x nll 4.000 PPL %.3f" % np.exp(4.0)
+    assert list(lm.losses["nll"]) == [2.0, 4.0] and len(lm.losses["nll"]) == 2

@@ -245,6 +245,14 @@ def test_latent_losses(ops, O):
             assert abs(float(mi_g) - float(mi_c)) <= 2e-6 + 1e-4 * abs(float(mi_c))   # difference of two entropies
             (reg_g * 1.7).backward()
             assert rel_err(lg.grad.cpu(), lc.grad) < 1e-5
+        # mi is a differentiable member of the reference's Pack (sent_models.py:155-158): its gradient, alone and mixed
+        lc = log_qy.clone().requires_grad_(True)
+        reg_c, bpr_c, mi_c = O.latent_losses(lc, y, k, True)
+        (mi_c * 0.9 + bpr_c * 0.3).backward()
+        lg = dev(log_qy).requires_grad_(True)
+        bpr_g, mi_g, _ = ops.LatentLossFunction.apply(lg, y, k, None)
+        (mi_g * 0.9 + bpr_g * 0.3).backward()
+        assert rel_err(lg.grad.cpu(), lc.grad) < 2e-5, rel_err(lg.grad.cpu(), lc.grad)
 
 
 @pytest.mark.parametrize("momentum", [0.0, 0.9])

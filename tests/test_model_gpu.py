@@ -239,6 +239,44 @@ def test_lazy_logprobs_materialize_matches_reference():
     assert rel_err(dense.cpu(), G["out/dec_logp"]) < 1e-5
 
 
+def test_loss_built_on_dense_logprobs_reaches_the_decoder():
+    """A caller may build its own loss on the dense [B,T,V] tensor DecoderRNN returns (decoders.py:165-166).  The lazy
+    handle's dense view is differentiable: the hand-made 'word' NLL below + reg_kl gives the reference's gradients for
+    every parameter (the same goldens the fused path is held to), not silently zero ones."""
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    G = load_golden("divae_tiny")
+    model, cfg = build(G, "divae")
+    model.train()
+    inject_u(model, G["in/u_steps"][0])
+    out_utts = torch.from_numpy(G["in/outputs"].astype(np.int64)).cuda()
+    log_qy, y_ids, h0 = model._encode_latent(out_utts, 1.0)
+    dec_outs, _, _ = model.decoder(out_utts.shape[0], out_utts[:, :-1], h0, mode=TEACH_FORCE)
+    labels = out_utts[:, 1:].contiguous()
+    dense = dec_outs.view(-1, dec_outs.size(-1))                     # tensor-style use -> materialised, on the tape
+    assert dense.requires_grad
+    picked = -dense.gather(1, labels.view(-1, 1)).squeeze(1)
+    mask = (labels.view(-1) != 0).float()
+    nll = (picked * mask).sum() / mask.sum()
+    assert close(nll, G["out/nll"])
+    reg_kl, _, _ = model.bpr_loss(log_qy)
+    model.zero_grad()
+    (nll + reg_kl).backward()
+    for n, p in model.named_parameters():
+        g = G["grad/" + n]
+        if g.size:
+            assert p.grad is not None and rel_err(p.grad.cpu(), g) < 2e-4, (n, rel_err(p.grad.cpu(), g))
+    # NLLEntropy on the dense tensor (laed_nll_gather_fwd/bwd) rides the same tape
+    model.zero_grad()
+    log_qy, y_ids, h0 = model._encode_latent(out_utts, 1.0)
+    dec_outs, _, _ = model.decoder(out_utts.shape[0], out_utts[:, :-1], h0, mode=TEACH_FORCE)
+    nll2 = model.nll_loss(dec_outs.view(out_utts.shape[0], -1, dec_outs.size(-1)), labels)
+    reg_kl, _, _ = model.bpr_loss(log_qy)
+    (nll2 + reg_kl).backward()
+    assert close(nll2, G["out/nll"])
+    assert rel_err(model.decoder.project.weight.grad.cpu(), G["grad/decoder.project.weight"]) < 2e-4
+    assert rel_err(model.x_encoder.rnn.weight_hh_l0.grad.cpu(), G["grad/x_encoder.rnn.weight_hh_l0"]) < 2e-4
+
+
 def test_latent_analysis_entry_points_vs_reference():
     """DiVAE.sweep / enumerate / exp_enumerate on the HIP decode loop: ids exact vs goldens from the reference."""
     G = load_golden("divae_gen_tiny")
