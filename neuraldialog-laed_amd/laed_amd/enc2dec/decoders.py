@@ -28,12 +28,13 @@ class LazyLogProbs(object):
         self.V = project.weight.shape[0]
         self.tok_nll = None
         self._dense = None
+        self._taped = torch.is_grad_enabled()     # a handle made under no_grad stays plain data, like the reference's tensor
 
     def materialize(self):
         """Dense [B,T,V] log-probs.  With the tape on and anything upstream requiring grad the tensor is differentiable
         (ops.DenseLogProbsFunction: a loss built on it reaches the decoder and the projection, as with the reference's
         tensor); under no_grad it is plain data.  The fused NLL path never materialises."""
-        needs_tape = torch.is_grad_enabled() and (self.h_tm.requires_grad or self.project.weight.requires_grad)
+        needs_tape = self._taped and torch.is_grad_enabled() and (self.h_tm.requires_grad or self.project.weight.requires_grad)
         if self._dense is not None and (self._dense.requires_grad or not needs_tape):
             return self._dense
         h_bf = self.h_tm.transpose(0, 1).reshape(self.B * self.T, -1)

@@ -107,10 +107,10 @@ def test_encoder_decoder_modules_vs_reference():
     with torch.no_grad():
         logp, hid, _ = dec(4, ids, h0, mode=TEACH_FORCE)
         gout, ghid, ret = dec(4, None, h0, mode=GEN, gen_type='greedy')
-    assert rel_err(logp.materialize().cpu(), G["dec/logp"]) < 1e-5 and rel_err(hid.cpu(), G["dec/hid"]) < 1e-5
+    assert rel_err(logp.materialize().detach().cpu(), G["dec/logp"]) < 1e-5 and rel_err(hid.cpu(), G["dec/hid"]) < 1e-5
     assert np.array_equal(torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy(), G["dec/gen_seq"])
     assert ret[DecoderRNN.KEY_LENGTH] == G["dec/gen_len"].tolist()
-    assert rel_err(gout.materialize().cpu(), G["dec/gen_logp"]) < 1e-5 and rel_err(ghid.cpu(), G["dec/gen_hid"]) < 1e-5
+    assert rel_err(gout.materialize().detach().cpu(), G["dec/gen_logp"]) < 1e-5 and rel_err(ghid.cpu(), G["dec/gen_hid"]) < 1e-5
 
 
 def _toy_dialogs(rs, n, V, T):

@@ -236,7 +236,8 @@ def test_lazy_logprobs_materialize_matches_reference():
     dec_outs, _, _ = model.decoder(out_utts.shape[0], out_utts[:, :-1], h0, mode=TEACH_FORCE)
     assert tuple(dec_outs.size()) == G["out/dec_logp"].shape and dec_outs.size(-1) == G["out/dec_logp"].shape[-1]
     dense = dec_outs.view(-1, dec_outs.size(-1)).view(G["out/dec_logp"].shape)
-    assert rel_err(dense.cpu(), G["out/dec_logp"]) < 1e-5
+    assert dense.requires_grad                       # on the tape: see test_loss_built_on_dense_logprobs_reaches_the_decoder
+    assert rel_err(dense.detach().cpu(), G["out/dec_logp"]) < 1e-5
 
 
 def test_loss_built_on_dense_logprobs_reaches_the_decoder():
