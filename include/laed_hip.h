@@ -15,7 +15,14 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
  *   - return value: 0 = ok, <0 = bad argument (LAED_E_*), >0 = hipError_t of a failed launch.
  *     laed_last_error() returns a thread-local description of the last non-zero status.
- *   - no global mutable state; reentrant across streams.
+ *   - reentrant across streams and threads.  Process-wide state is limited to: the GEMM math mode
+ *     (laed_set_gemm_mode, an atomic; default exact fp32), the opt-in GEMM profiler (laed_prof_*), per-device cached
+ *     device attributes, the allocation-free entry point's scratch array and the sticky timeout counter of the
+ *     persistent GRU kernels.  The product library reads four environment switches, once each:
+ *     LAED_GEMM_MODE, LAED_GRU_SMALL, LAED_GRU_PERSIST, LAED_GRU_WM (test hook); every other tuning override exists
+ *     only in the hooks build (make HOOKS=1).
+ *   - third-party device code on the path: rocPRIM's radix sort inside laed_embed_scatter_add (the deterministic
+ *     scatter-add sorts (id, position) pairs with it); everything else is this library's own kernels.
  */
 #ifndef LAED_HIP_H
 #define LAED_HIP_H

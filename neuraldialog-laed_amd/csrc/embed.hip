@@ -254,7 +254,7 @@ extern "C" int laed_embed_scatter_add(const int64_t* ids, int64_t rows, const fl
     LAED_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "embed_scatter_add: dropout p must be in [0,1)");
     if (rows == 0) return 0;
     LAED_CHECK_ARG(ids && dout && dtable, "embed_scatter_add: null pointer");
-    static const bool det_on = []() { const char* e = getenv("LAED_SCATTER_DET"); return !(e != nullptr && atoi(e) == 0); }();
+    static const bool det_on = []() { const char* e = laed_exp_hook("LAED_SCATTER_DET"); return !(e != nullptr && atoi(e) == 0); }();
     const float sc = 1.0f / (1.0f - drop_p);
     if (det_on && rows <= SC_SMALL) {
         hipLaunchKernelGGL(embed_scatter_small_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,

@@ -291,7 +291,7 @@ template <int WM, int WK, int NT = 256, int BKT = 32>
 int launch_step(const GruStepArgs& a, bool vec, hipStream_t stream) {
     GruStepArgs b = a;
     const unsigned mt = (a.B + 32 * WM - 1) / (32 * WM), jt = (a.H + 31) / 32;
-    static const int force_x = []() { const char* e = getenv("LAED_GRU_UNITS_IN_X"); return e ? atoi(e) : -1; }();
+    static const int force_x = []() { const char* e = laed_exp_hook("LAED_GRU_UNITS_IN_X"); return e ? atoi(e) : -1; }();
     b.units_in_x = force_x >= 0 ? force_x : 1;
     if (mt > 65535) b.units_in_x = 1;
     dim3 grid = b.units_in_x ? dim3(jt, mt) : dim3(mt, jt);

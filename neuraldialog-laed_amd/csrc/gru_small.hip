@@ -589,7 +589,7 @@ static int small_groups(int B) { return B <= 64 ? 1 : (B + 63) / 64; }
 bool laed_gru_small_ok(int B, int H) {
     if (!(small_enabled() && getenv("LAED_GRU_WM") == nullptr && B >= 1 && H >= 16 && (H % 16) == 0)) return false;
     if (B <= 64) return true;
-    static const bool mid = []() { const char* e = getenv("LAED_GRU_MID"); return !(e != nullptr && atoi(e) == 0); }();
+    static const bool mid = []() { const char* e = laed_exp_hook("LAED_GRU_MID"); return !(e != nullptr && atoi(e) == 0); }();
     return mid && B <= 512 && (int64_t)small_groups(B) * 3 * H * H * 4 <= ((int64_t)32 << 20);
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/laed_hip.h"
 
@@ -42,6 +43,16 @@ static inline bool laed_first_use_on_device(uint64_t* mask) {
     *mask |= (1ull << dev);
     return true;
 }
+
+// EXPERIMENT hooks (tile / split overrides, kernel-variant switches used by tools/*.py sweeps) are read from the
+// environment only in a hooks build (`make HOOKS=1`, -DLAED_ENV_HOOKS -> liblaed_hip_hooks.so, selected with
+// LAED_HIP_LIB); the product library compiles them to their defaults.  The four switches the product does read are
+// listed in INTEGRATION.md: LAED_GEMM_MODE, LAED_GRU_SMALL, LAED_GRU_PERSIST (operational) and LAED_GRU_WM (test hook).
+#ifdef LAED_ENV_HOOKS
+static inline const char* laed_exp_hook(const char* name) { return getenv(name); }
+#else
+static inline const char* laed_exp_hook(const char*) { return nullptr; }
+#endif
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

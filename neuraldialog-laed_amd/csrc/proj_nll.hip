@@ -382,7 +382,7 @@ template <int MODE>
 int launch_rows(float* L, int64_t rows, int V, int64_t ldl, const int64_t* labels, const float* row_scale, int64_t pad_id,
                 float* tok_nll, float* lse, hipStream_t stream) {
     const int64_t need = cdiv64(ldl / 4, 1024);     // float4 per thread for a register-resident row
-    static const bool reg_on = []() { const char* e = getenv("LAED_PROJ_ROWS_REG"); return !(e != nullptr && atoi(e) == 0); }();
+    static const bool reg_on = []() { const char* e = laed_exp_hook("LAED_PROJ_ROWS_REG"); return !(e != nullptr && atoi(e) == 0); }();
     const dim3 grid(rows_grid(rows));
 #define LAED_ROWS_REG(NV) hipLaunchKernelGGL((proj_rows_reg_kernel<MODE, NV>), grid, dim3(1024), 0, stream, L, rows, V, ldl, labels, \
                                              row_scale, pad_id, tok_nll, lse)

@@ -14,6 +14,7 @@
 // so the blocks resident on one XCD at a time share A row panels and walk the same B column panels.
 #include "laed_common.h"
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -25,10 +26,10 @@ namespace {
 // ---- optional live profiler (bench.py's roofline leg): HIP events around every GEMM launch, on the launch stream.
 // Off by default; when off the launch path touches none of this.  Variant id = layout*2 + (big tile ? 0 : 1).
 struct ProfRec { hipEvent_t start, stop; double flops; int variant; };
-int64_t g_xgemm_min_tiles = 192;   // bf16x3 mode: NT problems with at least this many 128x128 tiles use xgemm
-int g_gemm_mode = -1;   // -1 = not initialised (reads LAED_GEMM_MODE), 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x3) for NT
+std::atomic<int64_t> g_xgemm_min_tiles{192};   // bf16x3 mode: NT problems with at least this many 128x128 tiles use xgemm
+std::atomic<int> g_gemm_mode{-1};   // process-wide; -1 = not initialised (reads LAED_GEMM_MODE), 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x3) for NT
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 
@@ -36,17 +37,32 @@ std::vector<hipEvent_t> g_prof_pool;
 int big_tile_threads() {
     static int v = 0;
     if (v == 0) {
-        const char* e = getenv("LAED_GEMM_THREADS");
+        const char* e = laed_exp_hook("LAED_GEMM_THREADS");
         v = (e != nullptr && atoi(e) == 256) ? 256 : 512;
     }
     return v;
 }
 
-hipEvent_t prof_event() {
-    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
+bool prof_event(hipEvent_t* out) {       // g_prof_mu held
+    if (!g_prof_pool.empty()) { *out = g_prof_pool.back(); g_prof_pool.pop_back(); return true; }
+    return hipEventCreate(out) == hipSuccess;
+}
+
+// start a record: two events, the first recorded on `stream`.  false (and profiling switched off) if an event cannot
+// be created, so that no record with an uninitialised handle ever reaches laed_prof_collect
+bool prof_begin(ProfRec& r, double flops, int variant, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!prof_event(&r.start)) { g_prof_on = false; return false; }
+    if (!prof_event(&r.stop)) { g_prof_pool.push_back(r.start); g_prof_on = false; return false; }
+    r.flops = flops;
+    r.variant = variant;
+    (void)hipEventRecord(r.start, stream);
+    return true;
+}
+void prof_end(ProfRec& r, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(r.stop, stream);
+    g_prof_recs.push_back(r);
 }
 
 struct SgemmArgs {
@@ -460,17 +476,11 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     p.tiles_n = (a.N + BN - 1) / BN;
     int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
-    if (g_prof_on) {
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        ProfRec r;
-        r.start = prof_event();
-        r.stop = prof_event();
-        r.flops = 2.0 * a.M * a.N * a.K;
-        r.variant = (TA ? 2 : (TB ? 0 : 1)) * 2 + (BM == 128 ? 0 : 1);
-        (void)hipEventRecord(r.start, stream);
+    ProfRec r;
+    if (g_prof_on.load(std::memory_order_relaxed) && prof_begin(r, 2.0 * a.M * a.N * a.K,
+                                                               (TA ? 2 : (TB ? 0 : 1)) * 2 + (BM == 128 ? 0 : 1), stream)) {
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, p);
-        (void)hipEventRecord(r.stop, stream);
-        g_prof_recs.push_back(r);
+        prof_end(r, stream);
     } else {
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, p);
     }
@@ -484,11 +494,11 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
     const int nkt = (a.K + BK - 1) / BK;
-    if (g_gemm_mode < 0) (void)laed_get_gemm_mode();
+    const int gemm_mode = laed_get_gemm_mode();
     // opt-in split-bf16 math for the K-contiguous (NT) layout, 128x128 tiles (xgemm.hip).  An NT call that asks for
     // sums over K of A (colsum) can only be served by that kernel and forces it.
     const bool force_x = !TA && TB && a.colsum != nullptr;
-    const bool use_x = g_gemm_mode == 1 && !TA && TB && (force_x || t128 >= g_xgemm_min_tiles);
+    const bool use_x = gemm_mode == 1 && !TA && TB && (force_x || t128 >= g_xgemm_min_tiles);
     // Tile and split-K choice.  Problems of two rounds or more of the chip's 512 resident 128x128 blocks run as they
     // are (128x128, no split).  Below that a small cost model, fitted to tools/gemm_sweep.py on the mid-size products
     // of the reference's own batch sizes, prices every (tile, S):
@@ -539,7 +549,7 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
         S = force_split;
     }
     {   // experiment hook (tools/gemm_sweep.py): LAED_GEMM_FORCE="<tile>,<S>" overrides the choice above
-        static const char* fe = getenv("LAED_GEMM_FORCE");
+        static const char* fe = laed_exp_hook("LAED_GEMM_FORCE");
         if (fe != nullptr && !use_x) {
             int ft = 0, fs = 0;
             if (sscanf(fe, "%d,%d", &ft, &fs) == 2 && (ft == 64 || ft == 128) && fs >= 1) {
@@ -563,21 +573,11 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     int st;
     if (use_x) {
         ProfRec r;
-        if (g_prof_on) {
-            std::lock_guard<std::mutex> lk(g_prof_mu);
-            r.start = prof_event();
-            r.stop = prof_event();
-            r.flops = 2.0 * a.M * a.N * a.K;
-            r.variant = 6;
-            (void)hipEventRecord(r.start, stream);
-        }
+        // read the switch ONCE: a laed_prof_enable() between the two tests must not push a record without events
+        const bool prof = g_prof_on.load(std::memory_order_relaxed) && prof_begin(r, 2.0 * a.M * a.N * a.K, 6, stream);
         st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
                                   a.splitk, a.kper, a.ws, vec, S > 1 ? a.ws_colsum : a.colsum, a.colsum_acc != 0, stream);
-        if (g_prof_on) {
-            std::lock_guard<std::mutex> lk(g_prof_mu);
-            (void)hipEventRecord(r.stop, stream);
-            g_prof_recs.push_back(r);
-        }
+        if (prof) prof_end(r, stream);
     } else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
     else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
     else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
@@ -607,7 +607,7 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
     // rounds) spent 1/7 of its time on 56 tiles.  With workspace at hand the rows are cut so that the first launch
     // fills whole rounds and the remaining row tiles run as ONE more round with K split S ways (1/S as long),
     // summed in a fixed order like every other split-K product here.
-    static const bool tail_on = []() { const char* e = getenv("LAED_GEMM_TAILSPLIT"); return !(e != nullptr && atoi(e) == 0); }();
+    static const bool tail_on = []() { const char* e = laed_exp_hook("LAED_GEMM_TAILSPLIT"); return !(e != nullptr && atoi(e) == 0); }();
     if (tail_on && ws != nullptr && !raw_partials && M > 0 && N > 0 && K > 0 && A && B && C && !(transA && transB) &&
         laed_get_gemm_mode() == 0) {
         const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128, t = tm * tn;
@@ -713,11 +713,14 @@ extern "C" int laed_set_gemm_mode(int mode) {
     return 0;
 }
 extern "C" int laed_get_gemm_mode(void) {
-    if (g_gemm_mode < 0) {
+    int m = g_gemm_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
         const char* e = getenv("LAED_GEMM_MODE");
-        g_gemm_mode = (e != nullptr && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
+        m = (e != nullptr && (strcmp(e, "bf16x3") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
+        int expected = -1;
+        if (!g_gemm_mode.compare_exchange_strong(expected, m)) m = expected;     // a concurrent laed_set_gemm_mode wins
     }
-    return g_gemm_mode;
+    return m;
 }
 
 // ---- profiler C ABI (measurement aid; not part of the compute path)

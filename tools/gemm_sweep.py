@@ -3,7 +3,13 @@ VST: B=60; H=512, E=200, V~10004) against the launcher's heuristic.  Each forced
 (LAED_GEMM_FORCE is read once per process).   usage: gemm_sweep.py            (parent)
                                                       gemm_sweep.py child <M> <N> <K> <lay>"""
 import os, subprocess, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "neuraldialog-laed_amd"))
+_PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "neuraldialog-laed_amd")
+sys.path.insert(0, _PKG)
+# LAED_GEMM_FORCE is an experiment hook: only the hooks build reads it (make -C neuraldialog-laed_amd/csrc HOOKS=1)
+_HOOKS = os.path.join(_PKG, "laed_amd", "liblaed_hip_hooks.so")
+if not os.path.exists(_HOOKS):
+    raise SystemExit("gemm_sweep.py needs the hooks build: make -C neuraldialog-laed_amd/csrc HOOKS=1")
+os.environ.setdefault("LAED_HIP_LIB", _HOOKS)
 
 SHAPES = [("logits NT  P", 1170, 10004, 512, "NT"), ("logits NT  VST", 2340, 10004, 512, "NT"),
           ("dh NN      P", 1170, 512, 10004, "NN"), ("dh NN      VST", 2340, 512, 10004, "NN"),
