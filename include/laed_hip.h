@@ -209,8 +209,13 @@ int laed_cat_rows_bwd(const float* log_qy, const float* log_py, int64_t py_rows,
  *   if with_grad: dh[N][H] = dL/dh, dW[V][H] (+)=, db[V] (+)= for  L = sum_r row_scale[r]*tok_nll[r]
  *   workspace: laed_proj_nll_workspace(H, V, chunk_rows) floats (chunk_rows*ldl, ldl = laed_proj_nll_ldl(V), plus
  *       fp32 transposed operand copies when the split-bf16 GEMM mode is on)
- * ------------------------------------------------------------------------------------------ */
+ *   with_grad = 0 (validation, GEN-side callers; exact-fp32 mode): the logits are not written at all -- the logits
+ *       GEMM's epilogue keeps a (max, sum exp) pair per row per 128-column tile plus the label's logit, a second pass
+ *       combines them in tile order.  workspace: laed_proj_nll_fwd_workspace(N, V) = N*(2*ceil(V/128) + 1) floats
+ *       (62 MB at N = 19968, V = 50000, against 4.0 GB for the [N][V] tensor); chunk_rows is ignored.
+ */
 int     laed_proj_nll_ldl(int V);
+int64_t laed_proj_nll_fwd_workspace(int64_t N, int V);
 int64_t laed_proj_nll_workspace(int H, int V, int chunk_rows);   /* floats needed (depends on the GEMM math mode) */
 int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t* labels, const float* row_scale,
                   int64_t N, int H, int V, int64_t pad_id, int with_grad, int accumulate_w,

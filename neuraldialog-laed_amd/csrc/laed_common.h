@@ -72,6 +72,9 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
                            float* colsum_a, bool colsum_accumulate,
                            float* ws, int64_t ws_floats, bool raw_partials, int* splits_out, hipStream_t stream);
 
+int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                  const float* bias, const int64_t* labels, float* part, float* lab_logit, hipStream_t stream);
+
 extern "C" int laed_get_gemm_mode(void);
 int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float* C, int64_t ldc, const float* bias, bool accumulate,

@@ -219,6 +219,28 @@ __global__ __launch_bounds__(1024) void proj_rows_reg_kernel(float* __restrict__
     }
 }
 
+// Forward-only path: combine the per-tile (max, sum exp) partials the logits GEMM's online-softmax epilogue left in
+// part[tiles][rows][2] (tile order: fixed, reproducible) into lse and the token NLL.  One thread per row: consecutive
+// threads read consecutive rows of a tile's slab (coalesced float2).
+__global__ __launch_bounds__(256) void softmax_stats_combine_kernel(const float* __restrict__ part, const float* __restrict__ lab_logit,
+                                                                    int64_t rows, int tiles, int V, const int64_t* __restrict__ labels,
+                                                                    int64_t pad_id, float* __restrict__ tok_nll, float* __restrict__ lse_out) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        float m = -INFINITY, s = 0.f;
+        for (int t = 0; t < tiles; ++t) {
+            const float2 ps = *reinterpret_cast<const float2*>(part + ((int64_t)t * rows + r) * 2);
+            const float mm = fmaxf(m, ps.x);
+            s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (ps.x == -INFINITY ? 0.f : ps.y * expf(ps.x - mm));
+            m = mm;
+        }
+        const float lse = m + logf(s);
+        const int64_t lab = labels[r];
+        const bool ignored = lab == pad_id || lab < 0 || lab >= V;
+        if (lse_out) lse_out[r] = lse;
+        tok_nll[r] = ignored ? 0.f : lse - lab_logit[r];
+    }
+}
+
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ L, int64_t rows, int V, int64_t ldl,
                                                           int64_t* __restrict__ ids) {
     __shared__ float sv[4];
@@ -431,6 +453,14 @@ extern "C" int64_t laed_proj_nll_workspace(int H, int V, int chunk_rows) {
     return n;
 }
 
+// Workspace of a forward-only call (with_grad = 0) in the exact-fp32 mode: per-tile softmax partials + label logits,
+// O(rows * V/128) floats -- the logits are never written anywhere.  (The split-bf16 mode has no such epilogue and
+// keeps the chunked [chunk_rows][ldl] path: laed_proj_nll_workspace.)
+extern "C" int64_t laed_proj_nll_fwd_workspace(int64_t N, int V) {
+    const int64_t tiles = (V + 127) / 128;
+    return N * tiles * 2 + N;
+}
+
 extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t* labels, const float* row_scale,
                              int64_t N, int H, int V, int64_t pad_id, int with_grad, int accumulate_w,
                              float* workspace, int64_t ws_floats, int chunk_rows,
@@ -447,6 +477,23 @@ extern "C" int laed_proj_nll(const float* h, const float* W, const float* b, con
     LAED_CHECK_ARG(h && W && labels && workspace && tok_nll, "proj_nll: null pointer");
     LAED_CHECK_ARG(!with_grad || (dh && dW && db), "proj_nll: with_grad needs dh, dW, db");
     LAED_CHECK_ARG(aligned16(workspace), "proj_nll: workspace must be 16-byte aligned");
+    if (!with_grad && laed_get_gemm_mode() == 0 && N < 0x7fffffff) {
+        // forward only (validation, every GEN-side caller): ONE logits GEMM over all rows whose epilogue keeps, per
+        // 128-column tile, each row's (max, sum exp) and the label's logit; then a combine pass.  No [rows][V] tile
+        // exists at any point; chunk_rows is ignored.
+        const int64_t need = laed_proj_nll_fwd_workspace(N, V);
+        LAED_CHECK_ARG(ws_floats >= need, "proj_nll: forward-only workspace too small (%lld < %lld floats)",
+                       (long long)ws_floats, (long long)need);
+        const int tiles = (V + 127) / 128;
+        float* part = workspace;
+        float* lab_logit = workspace + (int64_t)N * tiles * 2;
+        LAED_TRY(laed_sgemm_softmax_stats_impl((int)N, V, H, h, H, W, H, b, labels, part, lab_logit, stream));
+        const int nblk = (int)(cdiv64(N, 256) < 4096 ? cdiv64(N, 256) : 4096);
+        hipLaunchKernelGGL(softmax_stats_combine_kernel, dim3(nblk), dim3(256), 0, stream, part, lab_logit, N, tiles, V, labels, pad_id,
+                           tok_nll, lse);
+        LAED_LAUNCH_CHECK("softmax_stats_combine");
+        return 0;
+    }
     const int64_t ldl = laed_proj_nll_ldl(V);
     LAED_CHECK_ARG(ws_floats >= laed_proj_nll_workspace(H, V, chunk_rows), "proj_nll: workspace too small (%lld < %lld floats)",
                    (long long)ws_floats, (long long)laed_proj_nll_workspace(H, V, chunk_rows));

@@ -15,6 +15,7 @@
 #include "laed_common.h"
 
 #include <atomic>
+#include <math.h>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -78,6 +79,10 @@ struct SgemmArgs {
     int splitk, kper;      // splitk > 1: block `split` covers K range [split*kper, min(K, (split+1)*kper)) and writes
     float* ws;             //   its raw partial tile to ws[split][M][N] (colsum partials to ws_colsum[split][M])
     float* ws_colsum;
+    // EPI == 1 (online-softmax epilogue, forward-only projection + NLL): C is never written; instead
+    const int64_t* labels; //   labels[M]
+    float* part;           //   part[tile_n][M][2] = (max, sum exp(x - max)) over the tile's columns of row m
+    float* lab_logit;      //   lab_logit[m] = logit[m][labels[m]] (written by the one lane that holds it)
 };
 
 constexpr int BK = 32;
@@ -149,7 +154,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0>
 __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmArgs p) {
     constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
     constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
@@ -387,6 +392,58 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmAr
         cur ^= 1;
     }
 
+    if (EPI == 1) {
+        // ---- online-softmax epilogue: per row of the block tile, (max, sum exp) over its BN columns and the label's
+        // logit; nothing else leaves the block.  A row's 32 columns of one MFMA tile sit in the 32 lanes that share
+        // lane>>5, so xor-shuffles up to 16 reduce them; the WGN waves that cover the tile's columns meet in LDS and are
+        // combined in wave order (fixed order: reproducible).
+        float* red = smem;                      // [WGN][BM][2]; every wave is past the main loop's last barrier
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                const int row = m0 + rl;
+                const int64_t lab = (row < p.M) ? p.labels[row] : -1;
+                float v[TN];
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * (BN / WGN) + j * 32 + lrow;
+                    v[j] = -INFINITY;
+                    if (col < p.N) {
+                        v[j] = acc[i][j][e] + (p.bias != nullptr ? p.bias[col] : 0.f);
+                        if ((int64_t)col == lab) p.lab_logit[row] = v[j];
+                    }
+                    m = fmaxf(m, v[j]);
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sum += (v[j] == -INFINITY) ? 0.f : expf(v[j] - m);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                if (lrow == 0) { red[(wn * BM + rl) * 2] = m; red[(wn * BM + rl) * 2 + 1] = sum; }
+            }
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float m = red[tid * 2], sum = red[tid * 2 + 1];
+#pragma unroll
+            for (int w = 1; w < WGN; ++w) {
+                const float m2 = red[(w * BM + tid) * 2], s2 = red[(w * BM + tid) * 2 + 1];
+                const float mm = fmaxf(m, m2);
+                sum = (m == -INFINITY ? 0.f : sum * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
+                m = mm;
+            }
+            float* dst = p.part + ((int64_t)tile_n * p.M + (m0 + tid)) * 2;
+            dst[0] = m;
+            dst[1] = sum;
+        }
+        return;
+    }
+
     // ---- epilogue: C/D map  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -460,11 +517,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs p) {
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0>
 int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
     constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
-    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT>;
+    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT, EPI>;
     static uint64_t attr_set = 0;   // per device
     if (laed_first_use_on_device(&attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -661,10 +718,30 @@ static int sgemm_dispatch(bool transA, bool transB, int M, int N, int K,
     a.colsum_acc = colsum_accumulate ? 1 : 0;
     a.tiles_m = a.tiles_n = 0;
     a.splitk = 1; a.kper = 0; a.ws = ws; a.ws_colsum = nullptr;
+    a.labels = nullptr; a.part = nullptr; a.lab_logit = nullptr;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (!transA && transB) return launch_layout<false, true>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
     if (!transA && !transB) return launch_layout<false, false>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
     return launch_layout<true, false>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
+}
+
+// Forward-only projection statistics: for x[M][K] W[N][K]^T + bias, per 128-column tile the (max, sum exp) of every row
+// and the logit at labels[m]; the [M][N] product itself is never written.  part: [ceil(N/128)][M][2] floats.
+int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                  const float* bias, const int64_t* labels, float* part, float* lab_logit, hipStream_t stream) {
+    LAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && labels && part && lab_logit, "sgemm_softmax_stats: bad argument");
+    LAED_CHECK_ARG(lda >= K && ldb >= K, "sgemm_softmax_stats: leading dimension too small");
+    SgemmArgs a;
+    a.A = A; a.B = B; a.C = nullptr; a.bias = bias; a.colsum = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = 0;
+    a.M = M; a.N = N; a.K = K;
+    a.accumulate = 0; a.colsum_acc = 0;
+    a.tiles_m = a.tiles_n = 0;
+    a.splitk = 1; a.kper = ((K + BK - 1) / BK) * BK; a.ws = nullptr; a.ws_colsum = nullptr;
+    a.labels = labels; a.part = part; a.lab_logit = lab_logit;
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    return vec ? launch_cfg<128, 128, false, true, true, 512, 1>(a, stream)
+               : launch_cfg<128, 128, false, true, false, 512, 1>(a, stream);
 }
 
 // NT product with row sums of A (bf16x3 mode only: the split-bf16 kernel sums its own A-operand registers).

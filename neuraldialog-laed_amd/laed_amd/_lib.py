@@ -53,6 +53,7 @@ _SIGS = {
     "laed_cat_rows_fwd": ([_p, _p, _i64, _i, _i64, _i, _f, _p, _p, _p, _p], _i),
     "laed_cat_rows_bwd": ([_p, _p, _i64, _i, _i64, _i, _p, _f, _p, _p, _p], _i),
     "laed_proj_nll_ldl": ([_i], _i),
+    "laed_proj_nll_fwd_workspace": ([_i64, _i], _i64),
     "laed_proj_nll_workspace": ([_i, _i, _i], _i64),
     "laed_proj_nll": ([_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _i, _i, _p, _i64, _i, _p, _p, _p, _p, _p, _p], _i),
     "laed_softmax_embed_workspace": ([_i, _i, _i], _i64),

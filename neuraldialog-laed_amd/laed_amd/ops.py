@@ -132,10 +132,15 @@ def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None)
     N, H = h.shape
     V = W.shape[0]
     dev = h.device
-    if chunk_rows is None:
-        chunk_rows = proj_chunk_rows(N, V, H)
-    ws_n = int(lib.laed_proj_nll_workspace(int(H), int(V), int(chunk_rows)))
-    ws = workspace("proj", ws_n, dev)
+    if not with_grad and get_gemm_mode() == "fp32":
+        # forward only: softmax partials per 128-column tile, O(rows * V / 128) floats; no logits tile at all
+        chunk_rows = max(1, N)
+        ws_n = max(4, int(lib.laed_proj_nll_fwd_workspace(int(N), int(V))))
+    else:
+        if chunk_rows is None:
+            chunk_rows = proj_chunk_rows(N, V, H)
+        ws_n = int(lib.laed_proj_nll_workspace(int(H), int(V), int(chunk_rows)))
+    ws = workspace("proj_fwd" if not with_grad else "proj", ws_n, dev)
     tok = torch.empty(N, device=dev, dtype=torch.float32)
     lse = torch.empty(N, device=dev, dtype=torch.float32)
     dh = dW = db = None

@@ -451,6 +451,41 @@ def test_proj_nll(ops, N, H, V, chunk):
     assert abs(float(red[0]) - float(tok_c.sum())) < 1e-4 * abs(float(tok_c.sum())) and float(red[1]) == cnt
 
 
+def test_forward_only_projection_never_writes_logits(ops):
+    """with_grad = 0 (validation / GEN-side callers): the logits GEMM's online-softmax epilogue keeps (max, sum exp) per
+    row per 128-column tile + the label's logit, so the workspace is O(rows * V/128) floats -- not O(rows * V) -- and
+    lse / token NLL still equal log_softmax + nll_loss (decoders.py:165-166, criterions.py:65-68).  Odd N / V / H,
+    an unaligned h view (scalar-load kernel variant), PAD and out-of-range labels, bitwise run-to-run equality."""
+    from laed_amd._lib import lib
+    for (N, H, V, unaligned) in ((1170, 128, 1003, False), (300, 72, 50000, False), (257, 37, 8203, True), (1, 16, 5, False)):
+        need = int(lib.laed_proj_nll_fwd_workspace(N, V))
+        tiles = (V + 127) // 128
+        assert need == N * (2 * tiles + 1)
+        assert need * 20 < N * V or V < 2000                 # ~V/64 floats per row instead of V
+        h, W, b = rnd(N, H, seed=1), rnd(V, H, seed=2, scale=0.3), rnd(V, seed=3, scale=0.1)
+        labels = torch.randint(1, V, (N,), generator=torch.Generator().manual_seed(4))
+        labels[::7] = 0
+        if N > 20:
+            labels[5], labels[11] = V + 3, -2                # outside [0,V): ignored like PAD (F.nll_loss would raise)
+        ok = (labels > 0) & (labels < V)
+        logits = h.double() @ W.double().t() + b.double()
+        lse_c = torch.logsumexp(logits, dim=1)
+        tok_c = (lse_c - logits.gather(1, labels.clamp(0, V - 1).view(-1, 1)).view(-1)) * ok
+        hd = dev(h)
+        if unaligned:                                         # H = 37: rows are not 16-byte aligned -> VEC = false variant
+            assert (hd.data_ptr() + 4 * H) % 16 != 0
+        ops._WS.clear()
+        tok, lse, dh, dW, db = ops.proj_nll_raw(hd, dev(W), dev(b), dev(labels), None, 0, False)
+        assert dh is None and dW is None and db is None
+        held = [t.numel() for k, t in ops._WS.items() if k[0].startswith("proj")]
+        assert held == [max(4, need)], (held, need)           # the only projection scratch this call made
+        assert rel_err(lse.cpu(), lse_c) < 1e-6
+        assert float((tok.cpu().double() - tok_c).abs().max()) <= 2e-5 * float(tok_c.abs().max() + 1.0)
+        assert float(tok.cpu()[~ok].abs().max()) == 0.0
+        tok2, lse2, _, _, _ = ops.proj_nll_raw(hd, dev(W), dev(b), dev(labels), None, 0, False)
+        assert torch.equal(tok, tok2) and torch.equal(lse, lse2)
+
+
 def test_proj_nll_bf16x3_mode(ops):
     """The projection+NLL pipeline under the opt-in split-bf16 GEMM mode (all three products as x W^T on transposed
     fp32 copies): same answers as the CPU reference to fp32-grade tolerance, two chunks, PAD rows, odd V."""
