@@ -120,6 +120,15 @@ def proj_chunk_rows(N, V, H=1024):
     # 8192-row ones at B = 4096, -0.4 % at B = 512 (one chunk), on a GPU with 288 GB
     # (the split-bf16 mode, whose transposed operand copies grow with the chunk, is 2.6 % faster with 2 GiB chunks)
     cap = max(1024, ((1 << 29) if get_gemm_mode() == "bf16x3" else (1 << 31)) // ldl)
+    # ... but never more than half of the [N, V] tensor once that tensor would be big (> 512 MiB): a rank that holds 512
+    # sequences of the scaled shape (N = 19968) must not materialise its whole 4 GB logits tensor just because it fits
+    # the cap.  Two 9984-row chunks cost +0.4 % step time there (59.68 -> 59.91 ms, tools/chunk_sweep.sh); chunks sized
+    # to the 256 MB Infinity Cache (1280 rows) cost +6.5 % (B = 512) / +8.6 % (B = 4096): the dW read-modify-write and
+    # the launch tails per chunk outweigh the cache hits, so chunks stay long.
+    if N * ldl * 4 > (512 << 20):
+        half = ((N + 1) // 2 + 127) // 128 * 128
+        if half <= cap:
+            return int(half)                                       # two balanced chunks
     if N <= cap:
         return int(max(N, 1))
     tiles_n = max(1, (H + 127) // 128)
