@@ -381,3 +381,16 @@ def test_engine_preview_generation_defaults_to_generate_with_an_evaluator(tmp_pa
     assert lm.pprint("x") == "x nll 3.000 PPL %.3f" % np.exp(3.0)
     assert lm.pprint("x", window=1, prefix="p") == "p: x nll 4.000 PPL %.3f" % np.exp(4.0)
     assert list(lm.losses["nll"]) == [2.0, 4.0] and len(lm.losses["nll"]) == 2
+
+
+def test_projection_chunks_never_hold_a_whole_big_logits_tensor():
+    """North-star item 2 at every config: once the [N, V] logits tensor would exceed 512 MiB, a training step's workspace
+    tile holds at most half of it (the 8-GPU point's per-rank N = 19968 at V = 50000 -> two 9984-row chunks), while
+    small problems keep one chunk."""
+    from laed_amd import ops
+    for N, V, H in ((19968, 50000, 1024), (159744, 50000, 1024), (40000, 50000, 1024), (79 * 512, 50000, 512)):
+        rows = ops.proj_chunk_rows(N, V, H)
+        assert rows <= (N + 1) // 2 + 127, (N, rows)
+        assert rows * ops.proj_ldl(V) * 4 <= (8 << 30) + (1 << 20)
+    assert ops.proj_chunk_rows(19968, 50000, 1024) == 9984
+    assert ops.proj_chunk_rows(1170, 10002, 512) == 1170 and ops.proj_chunk_rows(2496, 50000, 1024) == 2496
