@@ -155,7 +155,7 @@ def test_pack_and_cast_type():
 def test_proj_chunk_rows_fill_whole_cu_waves():
     from laed_amd.ops import proj_chunk_rows
     assert proj_chunk_rows(159744, 50000, 1024) == 40960        # 5 x (64 x 8 = 512 block tiles = 2 per CU)
-    assert proj_chunk_rows(19968, 50000, 1024) == 19968         # one GPU's share at 8 GPUs: one chunk
+    assert proj_chunk_rows(19968, 50000, 1024) == 9984          # one GPU's share at 8 GPUs: two balanced chunks, never the whole tensor
     assert proj_chunk_rows(1170, 10002, 512) == 1170            # small problem: one chunk
     r = proj_chunk_rows(10 ** 6, 50000, 512)
     assert r % 128 == 0 and r * 50016 * 4 <= (1 << 33)
