@@ -154,8 +154,36 @@ __device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const
     }
 }
 
+// C/D map of v_mfma_f32_32x32x2_f32:  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int BM, int BN, int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void store_acc(const SgemmArgs& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                          int lrow, int lk, int split) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WGN) + j * 32 + lrow;
+            const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row < p.M && col < p.N) {
+                    if (p.splitk > 1) {
+                        p.ws[((int64_t)split * p.M + row) * p.N + col] = acc[i][j][e];
+                    } else {
+                        float* dst = p.C + (int64_t)row * p.ldc + col;
+                        float v = acc[i][j][e] + bv;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0>
-__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmArgs p) {
+__device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
     constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
     constexpr int SA = BM + (AK ? 1 : 4);
@@ -444,29 +472,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmAr
         return;
     }
 
-    // ---- epilogue: C/D map  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / WGN) + j * 32 + lrow;
-            const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (row < p.M && col < p.N) {
-                    if (p.splitk > 1) {
-                        p.ws[((int64_t)split * p.M + row) * p.N + col] = acc[i][j][e];
-                    } else {
-                        float* dst = p.C + (int64_t)row * p.ldc + col;
-                        float v = acc[i][j][e] + bv;
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue
+    store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
 
     // ---- optional column sums of A (TA only): colsum[m] = sum_k A[k][m]
     if (TA) {
@@ -493,6 +500,202 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmAr
         }
     }
 }
+
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0>
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmArgs p) {
+    sgemm_block<BM, BN, TA, TB, VEC, NT, EPI>(p);
+}
+
+#ifdef LAED_ENV_HOOKS
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (hooks build only, LAED_GEMM_GLDS=1; measured and NOT adopted -- DESIGN.md section 4, "LDS-DMA, round 2").
+// LDS-DMA variant of the 128x128 / 8-wave kernel (interior blocks, 16-byte-loadable operands, K % 16 == 0).
+// The ablations of the register-staged loop above (tools/gemm_exp.py, dW shape with the tail split) price its staging at
+// 17 % of the kernel: 128 TF as built, 135 without the LDS stores, 141 without the global loads, 150 with neither --
+// while the fragment reads cost nothing.  Here neither operand ever touches a VGPR on its way in:
+//   * global_load_lds_dwordx4: each wave-instruction moves 1 KiB straight into LDS (lane-linear destination, per-lane
+//     source address), 2 instructions per wave per 16-deep K sub-tile (A piece + B piece);
+//   * a ring of NST = 4 sub-tile stages (64 KiB per block: still 2 blocks per CU); the DMA of sub-tile t+3 is issued at
+//     the top of sub-tile t and only has to land by the END of sub-tile t+1: counted s_waitcnt vmcnt(4) + raw s_barrier
+//     (a __syncthreads() would drain the DMA queue: vmcnt(0));
+//   * K-contiguous operands ([row][k] in memory) keep that order in LDS: image [128 rows][16 k], the four 16-byte quads
+//     of a row XOR-swizzled by (row >> 2) & 3 on the SOURCE address, so that one conflict-free ds_read_b128 hands a lane
+//     four k-values; the contraction is order-free, so MFMA step (g, j) takes k = 8g + 4*(lane>>5) + j from BOTH
+//     operands.  Other operands ([k][row] in memory) keep [16 k][128 rows] and are read with ds_read_b32 as before.
+// Edge blocks and K ranges that do not qualify run the register-staged block body above (same launch, same LDS).
+#define LAED_GPTR(x) ((const __attribute__((address_space(1))) void*)(x))
+#define LAED_LPTR(x) ((__attribute__((address_space(3))) void*)(x))
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void sgemm_glds_kernel(SgemmArgs p) {
+    constexpr int BM = 128, BN = 128, NT = 512, WGM = 2, WGN = 4, TM = 2, TN = 1;
+    constexpr int KS = 16, NST = 4;
+    constexpr bool AK = !TA, BKC = TB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    int nwg = gridDim.x, pid = blockIdx.x;
+    int xcd = pid & 7, q = nwg >> 3, r = nwg & 7;
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+    int split = 0;
+    if (p.splitk > 1) { split = wg % p.splitk; wg /= p.splitk; }
+    const int kbeg = split * p.kper;
+    const int kend = (p.splitk > 1) ? min(p.K, kbeg + p.kper) : p.K;
+    constexpr int GROUP_M = 8;
+    int in_group = GROUP_M * p.tiles_n;
+    int gid = wg / in_group, first_m = gid * GROUP_M;
+    int gsz = min(p.tiles_m - first_m, GROUP_M);
+    int tile_m = first_m + (wg % in_group) % gsz;
+    int tile_n = (wg % in_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int klen = kend - kbeg;
+    if (!((m0 + BM <= p.M) && (n0 + BN <= p.N) && klen >= KS * NST && (klen % KS) == 0)) {     // block-uniform
+        sgemm_block<BM, BN, TA, TB, true, NT, 0>(p);
+        return;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
+
+    float* imgA = smem;                         // [NST][BM * KS]
+    float* imgB = smem + NST * BM * KS;         // [NST][BN * KS]
+    const int nsub = klen / KS;
+
+    // per-lane source of this wave's 1-KiB piece of each operand's sub-tile image
+    const float* pa;
+    const float* pb;
+    int64_t pa_t, pb_t;
+    if (AK) {
+        const int row = 16 * wave + (lane >> 2), qs = (lane & 3) ^ ((row >> 2) & 3);
+        pa = p.A + (int64_t)(m0 + row) * p.lda + kbeg + 4 * qs; pa_t = KS;
+    } else {
+        pa = p.A + (int64_t)(kbeg + 2 * wave + (lane >> 5)) * p.lda + m0 + 4 * (lane & 31); pa_t = (int64_t)KS * p.lda;
+    }
+    if (BKC) {
+        const int row = 16 * wave + (lane >> 2), qs = (lane & 3) ^ ((row >> 2) & 3);
+        pb = p.B + (int64_t)(n0 + row) * p.ldb + kbeg + 4 * qs; pb_t = KS;
+    } else {
+        pb = p.B + (int64_t)(kbeg + 2 * wave + (lane >> 5)) * p.ldb + n0 + 4 * (lane & 31); pb_t = (int64_t)KS * p.ldb;
+    }
+    auto issue = [&](int stage, bool advance) {
+        __builtin_amdgcn_global_load_lds(LAED_GPTR(pa), LAED_LPTR(imgA + stage * BM * KS + wave * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(LAED_GPTR(pb), LAED_LPTR(imgB + stage * BN * KS + wave * 256), 16, 0, 0);
+        if (advance) { pa += pa_t; pb += pb_t; }
+    };
+
+    // fragment read offsets (floats) inside a stage image
+    const int arow = wm * (BM / WGM) + lrow, brow = wn * (BN / WGN) + lrow;
+    const int fsw = (lrow >> 2) & 3;            // (row >> 2) & 3: wave / MFMA-tile row offsets are multiples of 32
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        aoff[g] = AK ? arow * KS + 4 * ((2 * g + lk) ^ fsw) : (4 * (2 * g + lk)) * BM + arow;
+        boff[g] = BKC ? brow * KS + 4 * ((2 * g + lk) ^ fsw) : (4 * (2 * g + lk)) * BN + brow;
+    }
+    const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
+    const bool csum_wave = do_colsum && wn == 0;
+    float fsum[TM] = {0.f, 0.f};
+
+    // fragments of one sub-tile: fa[g][i][j], fb[g][j] for MFMA step (g, j)
+    struct Frag { float a[2][TM][4]; float b[2][4]; };
+    auto read_frags = [&](int tile, Frag& f) {
+        const float* a_s = imgA + (tile & (NST - 1)) * BM * KS;
+        const float* b_s = imgB + (tile & (NST - 1)) * BN * KS;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (AK) {
+                    const float4 v = *reinterpret_cast<const float4*>(a_s + aoff[g] + i * 32 * KS);
+                    f.a[g][i][0] = v.x; f.a[g][i][1] = v.y; f.a[g][i][2] = v.z; f.a[g][i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f.a[g][i][j] = a_s[aoff[g] + j * BM + i * 32];
+                }
+            }
+            if (BKC) {
+                const float4 v = *reinterpret_cast<const float4*>(b_s + boff[g]);
+                f.b[g][0] = v.x; f.b[g][1] = v.y; f.b[g][2] = v.z; f.b[g][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f.b[g][j] = b_s[boff[g] + j * BN];
+            }
+        }
+    };
+    auto mma_half = [&](const Frag& f, int g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][i][j], f.b[g][j], acc[i][0], 0, 0, 0);
+        if (TA && csum_wave) {                      // wave-uniform: column sums of A from this wave's own fragments
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fsum[i] += f.a[g][i][j];
+        }
+    };
+
+    // ---- prologue: sub-tiles 0..2 in flight, sub-tile 0 landed, its fragments in registers
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_) issue(s_, s_ + 1 < nsub);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frag f0, f1;
+    read_frags(0, f0);
+
+    // One sub-tile: first half of its MFMAs; then the ONE barrier of the step -- by then every wave holds all of this
+    // sub-tile's fragments in registers (they were read during the previous step) and, after the counted vmcnt, its
+    // pieces of sub-tile t+1 have landed -- so behind it sub-tile t+1 is readable and the stage of sub-tile t-1 is
+    // free: issue the DMA of sub-tile t+3 into it, read sub-tile t+1's fragments into the other register set, and run
+    // the second half of the MFMAs over those reads' latency.
+    auto step = [&](int t, const Frag& cur, Frag& nxt) {
+        mma_half(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(GLDS_EXP) || !(GLDS_EXP & 4)
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+#if !defined(GLDS_EXP) || !(GLDS_EXP & 1)
+        issue((t + NST - 1) & (NST - 1), t + NST < nsub);        // sub-tile t+3 (or a harmless re-load of the last one)
+#endif
+#if !defined(GLDS_EXP) || !(GLDS_EXP & 2)
+        if (t + 1 < nsub) read_frags(t + 1, nxt);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(cur, 1);
+    };
+    int t = 0;
+    for (; t + 1 < nsub; t += 2) {
+        step(t, f0, f1);
+        step(t + 1, f1, f0);
+    }
+    if (t < nsub) step(t, f0, f1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing re-loads must not outlive the block
+
+    store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
+    if (TA && csum_wave) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s_ = fsum[i] + __shfl_xor(fsum[i], 32, 64);          // the two k halves of the wave
+            if (lk == 0) {
+                const int m = m0 + wm * (BM / WGM) + i * 32 + lrow;
+                if (p.splitk > 1) p.ws_colsum[(int64_t)split * p.M + m] = s_;
+                else p.colsum[m] = p.colsum_acc ? p.colsum[m] + s_ : s_;
+            }
+        }
+    }
+}
+
+#endif   // LAED_ENV_HOOKS
 
 // C = sum_s ws[s] (+ bias) (+ C); colsum = sum_s ws_colsum[s] (+ colsum).  Fixed summation order: reproducible.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs p) {
@@ -544,6 +747,41 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     LAED_LAUNCH_CHECK("sgemm");
     return 0;
 }
+
+#ifdef LAED_ENV_HOOKS
+template <bool TA, bool TB>
+int launch_glds(const SgemmArgs& a, hipStream_t stream) {
+    constexpr size_t lds_glds = (size_t)4 * 2 * 128 * 16 * sizeof(float);
+    constexpr int SA = 128 + (!TA ? 1 : 4), SB = 128 + (TB ? 1 : 4);
+    constexpr size_t lds_reg = (size_t)2 * BK * (SA + SB) * sizeof(float);      // edge blocks: the register-staged body
+    constexpr size_t lds = lds_glds > lds_reg ? lds_glds : lds_reg;
+    auto kern = sgemm_glds_kernel<TA, TB>;
+    static uint64_t attr_set = 0;
+    if (laed_first_use_on_device(&attr_set)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return laed_fail((int)e, "sgemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    SgemmArgs p = a;
+    p.tiles_m = (a.M + 127) / 128;
+    p.tiles_n = (a.N + 127) / 128;
+    int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
+    if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
+    ProfRec r;
+    if (g_prof_on.load(std::memory_order_relaxed) && prof_begin(r, 2.0 * a.M * a.N * a.K, (TA ? 2 : (TB ? 0 : 1)) * 2, stream)) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, p);
+        prof_end(r, stream);
+    } else {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, p);
+    }
+    LAED_LAUNCH_CHECK("sgemm_glds");
+    return 0;
+}
+
+bool glds_on() {
+    static const bool v = []() { const char* e = laed_exp_hook("LAED_GEMM_GLDS"); return e != nullptr && atoi(e) == 1; }();
+    return v;
+}
+#endif
 
 template <bool TA, bool TB>
 int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, int* splits_out, int force_split,
@@ -635,7 +873,15 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
         st = laed_xgemm_nt_launch(a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.bias, a.accumulate != 0,
                                   a.splitk, a.kper, a.ws, vec, S > 1 ? a.ws_colsum : a.colsum, a.colsum_acc != 0, stream);
         if (prof) prof_end(r, stream);
-    } else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
+    }
+#ifdef LAED_ENV_HOOKS
+    else if (big && vec && S == 1 && t128 >= 2048 && laed_exp_hook("LAED_GEMM_TILE256") != nullptr)
+        st = launch_cfg<256, 256, TA, TB, true, 1024>(a, stream);      // experiment: 16 waves, 256x256 tile, one block per CU
+#endif
+#ifdef LAED_ENV_HOOKS
+    else if (big && vec && glds_on() && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB>(a, stream);
+#endif
+    else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
     else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
     else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);
     if (st != 0 || S == 1 || raw_partials) return st;

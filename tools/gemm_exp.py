@@ -3,7 +3,8 @@ usage: python tools/gemm_exp.py lib1.so lib2.so ...   (each a full liblaed_hip b
 import ctypes, sys, torch
 
 SHAPES = [("NT logits", 8192, 50000, 1024, 0, 1), ("NN dh", 8192, 1024, 50000, 0, 0), ("TN dW", 50000, 1024, 8192, 1, 0),
-          ("NT square", 8192, 8192, 8192, 0, 1)]
+          ("NT square", 8192, 8192, 8192, 0, 1), ("TN dW K=40960", 50000, 1024, 40960, 1, 0),
+          ("NT logits M=40960", 40960, 50000, 1024, 0, 1), ("NN dh M=40960", 40960, 1024, 50000, 0, 0)]
 
 
 def run(path):
