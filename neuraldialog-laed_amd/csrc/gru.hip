@@ -28,27 +28,29 @@ struct GruStepArgs {
 
 // WM row tiles x WK K-splits = NT/64 waves (4 waves with K tiles of 32, or 8 waves with K tiles of 64: in both a load
 // pass covers 32 rows, i.e. the h tile in WM passes and one gate block of the W tile per pass)
-template <int WM, int WK, bool VEC, int NT = 256, int BK = 32>
+// WU unit tiles per block (WU = 2: 64 hidden units x 3 gates = 192 columns): the W_hh tile is then shared by more MFMAs
+// per staged byte -- (BR + 96 WU) * 128 bytes per K tile for 3 * WM * WU * 16 MFMAs: 213 B/MFMA for 64 x 96,
+// 107 B/MFMA for 128 x 192 (the 128 x 128 GEMM tile: 128) -- which is what the GEMM ablations say the loss scales with.
+template <int WM, int WK, bool VEC, int NT = 256, int BK = 32, int WU = 1>
 __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
-    static_assert(WM * WK * 64 == NT && NT / (BK / 4) == 32, "geometry");
+    static_assert(WM * WU * WK * 64 == NT && NT / (BK / 4) == 32 * WU, "geometry");
     constexpr int BR = 32 * WM;        // batch rows per block
+    constexpr int UB = 32 * WU;        // hidden units per block
     constexpr int SH = BR + 1;         // K-contiguous operands: transposing b32 writes, pad 1
-    constexpr int SW = 96 + 1;
+    constexpr int SW = 3 * UB + 1;
+    constexpr int RPP = NT / (BK / 4); // tile rows covered by one load pass (= UB: one gate block of the W tile)
     constexpr int NLH = BR * BK / 4 / NT > 0 ? BR * BK / 4 / NT : 1;   // float4 per thread (h tile)
-    constexpr int NLW = 96 * BK / 4 / NT;                                // = 3
-    constexpr int TILE = BK * (SH + SW);
-    constexpr int RED = (WK > 1) ? WK * WM * 64 * 48 : 0;
-    constexpr int SMEM = (2 * TILE > RED) ? 2 * TILE : RED;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    constexpr int NLW = 3 * UB * BK / 4 / NT;                            // = 3
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sH = smem;                  // [2][BK][SH]
     float* sW = smem + 2 * BK * SH;    // [2][BK][SW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wq = wave / WM;
+    const int wm = wave % WM, wu = (wave / WM) % WU, wq = wave / (WM * WU);
     // blocks are dealt round-robin over the 8 XCDs by their linear id: with the unit tile in blockIdx.x the blocks of one
     // XCD share 1/8 of the W_hh slices (L2-resident) and differ in their batch rows; with the row tile in blockIdx.x
     // every XCD streams ALL of W_hh each step (12.6 MB at H = 1024: more than its 4 MB L2)
-    const int m0 = (p.units_in_x ? blockIdx.y : blockIdx.x) * BR, j0 = (p.units_in_x ? blockIdx.x : blockIdx.y) * 32;
+    const int m0 = (p.units_in_x ? blockIdx.y : blockIdx.x) * BR, j0 = (p.units_in_x ? blockIdx.x : blockIdx.y) * UB;
     const int B = p.B, H = p.H;
 
     f32x16 acc[3];
@@ -66,14 +68,14 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     constexpr int EPW = 16 / EW;
     float pre[EPW][4];
     float bhr = 0.f, bhz = 0.f, bhn = 0.f;
-    if (tid / 64 / WM < EW) {
-        const int jj = j0 + (tid & 31);
+    if (wq < EW) {
+        const int jj = j0 + wu * 32 + (tid & 31);
         if (jj < H) {
             bhr = p.b_hh[jj]; bhz = p.b_hh[H + jj]; bhn = p.b_hh[2 * H + jj];
 #pragma unroll
             for (int ee = 0; ee < EPW; ++ee) {
-                const int e = (tid / 64 / WM) * EPW + ee;
-                const int row = m0 + (tid / 64 % WM) * 32 + (e & 3) + 8 * (e >> 2) + 4 * ((tid & 63) >> 5);
+                const int e = wq * EPW + ee;
+                const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * ((tid & 63) >> 5);
                 if (row < B) {
                     const float* g = p.gates + (int64_t)row * 3 * H;
                     pre[ee][0] = g[jj]; pre[ee][1] = g[H + jj]; pre[ee][2] = g[2 * H + jj];
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
             int idx = tid + i * NT;
-            int row = idx / (BK / 4), kq = idx % (BK / 4);   // row in [0,96): gate = row/32, unit = row%32
-            int unit = j0 + (row & 31), gk = k0 + 4 * kq;
+            int row = idx / (BK / 4), kq = idx % (BK / 4);   // row in [0, 3 UB): gate = row / UB, unit = row % UB
+            int unit = j0 + (row % UB), gk = k0 + 4 * kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (unit < H && gk < H) {
-                const float* src = p.w_hh + ((int64_t)(row >> 5) * H + unit) * H + gk;
+                const float* src = p.w_hh + ((int64_t)(row / UB) * H + unit) * H + gk;
                 if (VEC && gk + 3 < H) v = *reinterpret_cast<const float4*>(src);
                 else { v.x = src[0]; if (gk + 1 < H) v.y = src[1]; if (gk + 2 < H) v.z = src[2]; if (gk + 3 < H) v.w = src[3]; }
             }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     const int nkt = (H + BK - 1) / BK;
     const int lrow = lane & 31, lk = lane >> 5;
     // interior blocks: scheduled loop (see sgemm.hip) -- loads / LDS reads / LDS stores sit in the MFMA issue gaps
-    const bool interior = VEC && (m0 + BR <= B) && (j0 + 32 <= H);
+    const bool interior = VEC && (m0 + BR <= B) && (j0 + UB <= H);
     const int nfull = H / BK;
     const bool fast = interior && nfull > 0;
     constexpr int KS = BK / 2 / WK;            // k pairs per wave per K tile
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     constexpr int NL = NLH + NLW;
     const float* gh = p.hprev + (int64_t)(m0 + tid / (BK / 4)) * H + 4 * (tid % (BK / 4));
     const float* gw = p.w_hh + (int64_t)(j0 + tid / (BK / 4)) * H + 4 * (tid % (BK / 4));
-    const int64_t h_ist = (int64_t)32 * H, w_ist = (int64_t)H * H;   // 32 rows per pass; one gate block per pass
+    const int64_t h_ist = (int64_t)RPP * H, w_ist = (int64_t)H * H;   // RPP rows per pass; one gate block per pass
     const int s_off_h = (4 * (tid % (BK / 4))) * SH + tid / (BK / 4);
     const int s_off_w = (4 * (tid % (BK / 4))) * SW + tid / (BK / 4);
     auto load_unit = [&](int u) {
@@ -155,11 +157,11 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     };
     auto store_unit = [&](int u, int buf) {
         if (u < NLH) {
-            float* d = sH + buf * BK * SH + s_off_h + u * 32;
+            float* d = sH + buf * BK * SH + s_off_h + u * RPP;
             d[0] = rh[u].x; d[SH] = rh[u].y; d[2 * SH] = rh[u].z; d[3 * SH] = rh[u].w;
         } else {
             const int v = u - NLH;
-            float* d = sW + buf * BK * SW + s_off_w + v * 32;
+            float* d = sW + buf * BK * SW + s_off_w + v * RPP;
             d[0] = rw[v].x; d[SW] = rw[v].y; d[2 * SW] = rw[v].z; d[3 * SW] = rw[v].w;
         }
     };
@@ -185,11 +187,11 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         for (int u = 0; u < NL; ++u) load_unit(u);
         for (; kt + 1 < nfull; ++kt) {
             const float* h_s = sH + cur * BK * SH + wm * 32 + lrow + (2 * wq + lk) * SH;
-            const float* w_s = sW + cur * BK * SW + lrow + (2 * wq + lk) * SW;
+            const float* w_s = sW + cur * BK * SW + wu * 32 + lrow + (2 * wq + lk) * SW;
             if (kt + 2 < nfull) { gh += BK; gw += BK; }
             float af[2], bf[2][3];
             af[0] = h_s[0];
-            bf[0][0] = w_s[0]; bf[0][1] = w_s[32]; bf[0][2] = w_s[64];
+            bf[0][0] = w_s[0]; bf[0][1] = w_s[UB]; bf[0][2] = w_s[2 * UB];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 #if !defined(GRU_EXP) || !(GRU_EXP & 4)
                         const int o = 2 * (ks + 1) * WK;
                         af[(ks + 1) & 1] = h_s[o * SH];
-                        bf[(ks + 1) & 1][0] = w_s[o * SW]; bf[(ks + 1) & 1][1] = w_s[o * SW + 32]; bf[(ks + 1) & 1][2] = w_s[o * SW + 64];
+                        bf[(ks + 1) & 1][0] = w_s[o * SW]; bf[(ks + 1) & 1][1] = w_s[o * SW + UB]; bf[(ks + 1) & 1][2] = w_s[o * SW + 2 * UB];
 #else
                         af[(ks + 1) & 1] = af[ks & 1];
                         bf[(ks + 1) & 1][0] = bf[ks & 1][0]; bf[(ks + 1) & 1][1] = bf[ks & 1][1]; bf[(ks + 1) & 1][2] = bf[ks & 1][2];
@@ -227,12 +229,12 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         const bool more = kt + 1 < nkt;
         if (more) load((kt + 1) * BK);
         const float* h_s = sH + cur * BK * SH + wm * 32 + lrow;
-        const float* w_s = sW + cur * BK * SW + lrow;
+        const float* w_s = sW + cur * BK * SW + wu * 32 + lrow;
 #pragma unroll
         for (int ks = 0; ks < BK / 2 / WK; ++ks) {
             const int krow = 2 * (wq + ks * WK) + lk;
             float a = h_s[krow * SH];
-            float b0 = w_s[krow * SW], b1 = w_s[krow * SW + 32], b2 = w_s[krow * SW + 64];
+            float b0 = w_s[krow * SW], b1 = w_s[krow * SW + UB], b2 = w_s[krow * SW + 2 * UB];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 
     if (WK > 1) {   // every wave hands the rows it does not own to their owners (fixed summation order: wq ascending)
         float* red = smem;   // all waves are past the last barrier: tiles are dead
-        float* d = red + ((wq * WM + wm) * 48) * 64 + lane;
+        float* d = red + ((wq * WM * WU + wu * WM + wm) * 48) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 #pragma unroll
         for (int s = 0; s < WK; ++s) {
             if (s == wq) continue;
-            const float* sp = red + ((s * WM + wm) * 48) * 64 + lane;
+            const float* sp = red + ((s * WM * WU + wu * WM + wm) * 48) * 64 + lane;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         }
     }
 
-    const int j = j0 + lrow;
+    const int j = j0 + wu * 32 + lrow;
     if (j >= H) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -287,16 +289,27 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     }
 }
 
-template <int WM, int WK, int NT = 256, int BKT = 32>
+template <int WM, int WK, int NT = 256, int BKT = 32, int WU = 1>
 int launch_step(const GruStepArgs& a, bool vec, hipStream_t stream) {
     GruStepArgs b = a;
-    const unsigned mt = (a.B + 32 * WM - 1) / (32 * WM), jt = (a.H + 31) / 32;
+    const unsigned mt = (a.B + 32 * WM - 1) / (32 * WM), jt = (a.H + 32 * WU - 1) / (32 * WU);
+    constexpr int TILE = BKT * (32 * WM + 1 + 96 * WU + 1);
+    constexpr int RED = (WK > 1) ? WK * WM * WU * 64 * 48 : 0;
+    constexpr size_t lds = sizeof(float) * ((2 * TILE > RED) ? 2 * TILE : RED);
+    static uint64_t attr_set = 0;       // per device (and per instantiation: the static lives in the template)
+    if (lds > 48 * 1024 && laed_first_use_on_device(&attr_set)) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<WM, WK, true, NT, BKT, WU>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<WM, WK, false, NT, BKT, WU>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return laed_fail((int)(e1 != hipSuccess ? e1 : e2), "gru_step: hipFuncSetAttribute failed");
+    }
     static const int force_x = []() { const char* e = laed_exp_hook("LAED_GRU_UNITS_IN_X"); return e ? atoi(e) : -1; }();
     b.units_in_x = force_x >= 0 ? force_x : 1;
     if (mt > 65535) b.units_in_x = 1;
     dim3 grid = b.units_in_x ? dim3(jt, mt) : dim3(mt, jt);
-    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true, NT, BKT>), grid, dim3(NT), 0, stream, b);
-    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false, NT, BKT>), grid, dim3(NT), 0, stream, b);
+    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true, NT, BKT, WU>), grid, dim3(NT), lds, stream, b);
+    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false, NT, BKT, WU>), grid, dim3(NT), lds, stream, b);
     LAED_LAUNCH_CHECK("gru_step_fwd");
     return 0;
 }
@@ -310,10 +323,19 @@ int gru_step(const GruStepArgs& a, hipStream_t stream) {
     if (forced_wm == 2) return launch_step<2, 2>(a, vec, stream);
     if (forced_wm == 1) return launch_step<1, 4>(a, vec, stream);
     if (forced_wm == 8) return launch_step<2, 4, 512, 64>(a, vec, stream);
+    // two-unit-tile geometries (half the staged bytes per MFMA), measured in round 2 and not selected: the step kernel's
+    // loss sits outside its 32-tile K loop (gate operands / results, block start-up), not in the staging -- us per step
+    // at H = 1024, B = 4096 incl. the input GEMM's share: 64x96 299.6, 128x96 293.1, 128x192 298.5, 64x192 (K split) 306.9
+    if (forced_wm == 42) return launch_step<4, 1, 512, 32, 2>(a, vec, stream);     // 128 rows x 64 units, one block per CU
+    if (forced_wm == 22) return launch_step<2, 2, 512, 32, 2>(a, vec, stream);     //  64 rows x 64 units, K split 2
     // measured at H = 1024 (tools/gru_geom.py, us/step incl. the input GEMM share, B = 256 / 512 / 2048 / 4096):
     //   128-row tiles 92 / 98 / 173 / 333,  64-row tiles 51 / 56 / 161 / 309,  32-row tiles (K split 4 ways) 39 / 70 / 256 / -
     // 64-row tiles (41 KB of LDS: three blocks = 12 waves per CU) win from one block per CU upwards; smaller batches
     // split K over all four waves of a 32-row tile instead.
+    // from two full rounds of 128-row tiles upwards (2 blocks per CU: 512 slots) those win by 2-3 % (round 2, same
+    // script: B = 2048 148.5 vs 153.3, B = 4096 293.1 vs 299.6): 1024 blocks are exactly two rounds, where the 2048
+    // 64-row blocks run as 2.67 rounds of 3 per CU
+    if (cdiv64(a.B, 128) * jt >= 512) return launch_step<4, 1>(a, vec, stream);
     if (a.B > 32 && cdiv64(a.B, 64) * jt >= 256) return launch_step<2, 2>(a, vec, stream);
     return launch_step<1, 4>(a, vec, stream);
 }

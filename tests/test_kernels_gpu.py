@@ -201,9 +201,9 @@ def test_gru_mid_batch_row_groups(ops, O, T, B, E, H, with_h0):
 def test_gru_all_tile_configs(ops, O):
     # the block-tile choice is a pure launch-geometry decision: every forced config must agree
     try:
-        for wm in ("4", "2", "1", "8"):
+        for wm in ("4", "2", "1", "8", "42", "22"):
             os.environ["LAED_GRU_WM"] = wm
-            _gru_case(ops, O, 3, 260, 32, 64, True, seed=20, tol=1e-5)
+            _gru_case(ops, O, 3, 260, 32, 96, True, seed=20, tol=1e-5)
             _gru_case(ops, O, 2, 5, 8, 40, False, seed=21, tol=1e-5)
     finally:
         os.environ.pop("LAED_GRU_WM", None)
