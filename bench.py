@@ -51,18 +51,24 @@ SHAPES = {
 DIALOG_CTX = 10
 
 
-TRAFFIC_NOTE = ("profiles/r1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                "(tools/pmc_traffic.py; KiB*1024, FETCH doubled per the gfx950 note), bytes per launch, L3 hits included")
+TRAFFIC_NOTE = ("profiles/r2_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                "(tools/pmc_traffic.py; KiB*1024, FETCH doubled per the gfx950 note), L2<->fabric bytes per launch of the "
+                "variant's largest launch shape (the projection product; algorithmic bytes of that launch: dW TN 8.4 GB, "
+                "dh NN 8.4 GB, logits NT 8.6 GB with 40960-row chunks), Infinity-Cache hits included; committed file, not "
+                "re-measured in this run (PMC passes serialise kernels)")
 
 
 def pmc_traffic(variant, same_job):
     """Per-launch L2<->fabric bytes of `variant` from the committed PMC passes of this same job (S-fixed, 1 GPU);
     None for any other job (the counters cannot be collected inside a normal run)."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
     if not same_job or not os.path.exists(path):
         return None
     try:
-        return json.load(open(path))["variants"][variant]["bytes_per_launch"]
+        v = json.load(open(path))["variants"][variant]
+        # the variant's launches are dissimilar (projection product, its split-K tail, GRU products): report the launch
+        # shape that moves the most bytes -- the projection product itself -- not an average over all of them
+        return v.get("largest_launch", v)["bytes_per_launch"]
     except (KeyError, ValueError):
         return None
 

@@ -85,7 +85,10 @@ struct SgemmArgs {
     float* lab_logit;      //   lab_logit[m] = logit[m][labels[m]] (written by the one lane that holds it)
 };
 
-constexpr int BK = 32;
+#ifndef SGEMM_BK
+#define SGEMM_BK 32
+#endif
+constexpr int BK = SGEMM_BK;   // K tile depth (16 measured in round 2: more blocks per CU)
 
 // Load a (BR rows) x (BK k) tile into registers as float4s.
 //  KCONTIG: element (r,k) at P[r*ld + k]   -> each thread takes 4 consecutive k of one row

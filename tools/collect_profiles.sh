@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): every measurement profiles/ is built from, into gpurun_out/final/.
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
-# then, back in the build container:  python tools/publish_profiles.py r1
+# then, back in the build container:  python tools/publish_profiles.py r2
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final

@@ -66,10 +66,17 @@ def main():
         sel = [r for r in rows if re.search(pat, r["kernel"])]
         n = sum(r["launches"] for r in sel)
         if n:
+            # a variant covers dissimilar launches (the projection product, its split-K tail, the GRU products): the
+            # average over them means little, so the launch shape that moves the most bytes is reported on its own
+            top = max(sel, key=lambda r: (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"])
             variants[vname] = {
                 "launches": n,
                 "bytes_per_launch": round(sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"]
-                                              for r in sel) / n)}
+                                              for r in sel) / n),
+                "largest_launch": {"workgroups": top["workgroups"], "launches": top["launches"],
+                                   "fetch_bytes_per_launch": top["fetch_bytes_per_launch"],
+                                   "write_bytes_per_launch": top["write_bytes_per_launch"],
+                                   "bytes_per_launch": top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"]}}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
                          "`python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0`",
                "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950, 16 B/lane reads); includes Infinity-Cache hits",
