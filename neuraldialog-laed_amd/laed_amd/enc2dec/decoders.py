@@ -120,6 +120,62 @@ class DecoderRNN(BaseRNN):
         out_tm, hT = self.rnn.forward_tm(embedded.transpose(0, 1), None if hidden is None else hidden[0])
         return LazyLogProbs(out_tm, self.project, B), hT.unsqueeze(0), None
 
+    def _beam_search(self, batch_size, init_state, beam_size):
+        """gen_type='beam' (decoders.py:194-202, 222-235, 270-291), the reference's algorithm as written:
+          * the initial state is repeated beam_size times per sequence (repeat_state: rows b*beam + j);
+          * step 0 ranks only slot 0's V scores (all slots are identical); later steps rank cum_sum + log-probs over the
+            beam*V candidates of a sequence; back pointer = candidate // V, symbol = candidate % V;
+          * the chosen symbols are fed back slot by slot, but the HIDDEN STATES ARE NOT REORDERED by the back pointers
+            (the reference never gathers decoder_hidden) -- reproduced, not fixed;
+          * after max_length steps the best final slot is traced back through the back pointers to the 1-best sequence;
+          * `length` has one entry per (sequence, slot): first step at which that slot emitted EOS.
+        Parity is UNPINNED: the reference's own back-tracking does not run under Python 3 / torch >= 0.4
+        (`torch.cat` of 0-d tensors, true division in `top_id.div`), so this is checked against the oracle's restatement
+        only (oracle.decoder_beam).  Per step: embedding gather, GRU cell, projection and log-softmax on the HIP
+        kernels; candidate ranking is torch.topk on the device (selection, GEN-side only)."""
+        B, K, V, L = batch_size, int(beam_size), self.output_size, self.max_length
+        with torch.no_grad():
+            h = init_state[0].detach().contiguous().repeat_interleave(K, dim=0).contiguous()        # [B*K, H]
+            dev = h.device
+            symbols = torch.full((B * K,), int(self.sos_id), dtype=torch.int64, device=dev)
+            W, bias = self.project.weight.detach(), self.project.bias.detach()
+            rnn = self.rnn
+            cum_sum = None
+            steps, back_ptrs, hiddens = [], [], []
+            for di in range(L):
+                x = self.embedding(symbols.view(-1, 1)).reshape(B * K, -1).contiguous()
+                h = ops.gru_cell(x, rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach(), rnn.bias_ih_l0.detach(),
+                                 rnn.bias_hh_l0.detach(), h)
+                hiddens.append(h)
+                buf = ops.logits_rows(h, W, bias)
+                ops.log_softmax_rows_(buf, V)
+                logp = buf[:, :V]
+                if di == 0:
+                    seq_score = logp.reshape(B, K * V)[:, :V]
+                else:
+                    seq_score = (cum_sum + logp).reshape(B, K * V)
+                top_v, top_id = seq_score.topk(K)
+                back_ptrs.append(torch.div(top_id, V, rounding_mode='floor'))        # [B, K]
+                symbols = torch.remainder(top_id, V).reshape(-1)
+                cum_sum = top_v.reshape(-1, 1)
+                steps.append(symbols.view(B, K))
+            all_sym = torch.stack(steps).cpu().numpy()                               # [L, B, K], one copy
+            all_bp = torch.stack(back_ptrs).cpu().numpy()
+            best = cum_sum.view(B, K).topk(1)[1].view(-1).cpu().numpy()
+        lengths = np.array([L] * (B * K))
+        for di in range(L):                                                          # decoders.py:241-245
+            eos = all_sym[di].reshape(-1) == self.eos_id
+            lengths[(lengths > di) & eos] = di + 1
+        rows = np.arange(B)
+        final = np.zeros((B, L), dtype=np.int64)
+        for di in range(L - 1, -1, -1):                                              # back-tracking
+            final[:, di] = all_sym[di][rows, best]
+            best = all_bp[di][rows, best]
+        seq = torch.from_numpy(final).to(dev)
+        ret_dict = {DecoderRNN.KEY_SEQUENCE: [seq[:, t:t + 1] for t in range(L)], DecoderRNN.KEY_LENGTH: lengths.tolist()}
+        decoder_outputs = LazyLogProbs(torch.stack(hiddens), self.project, B * K)
+        return decoder_outputs, h.unsqueeze(0), ret_dict
+
     def forward(self, batch_size, inputs=None, init_state=None, attn_context=None, mode=TEACH_FORCE,
                 gen_type='greedy', beam_size=4):
         ret_dict = dict()
@@ -132,9 +188,10 @@ class DecoderRNN(BaseRNN):
             ret_dict[DecoderRNN.KEY_SEQUENCE] = []
             ret_dict[DecoderRNN.KEY_LENGTH] = [self.max_length] * batch_size
             return decoder_outputs, decoder_hidden, ret_dict
+        if gen_type == 'beam':
+            return self._beam_search(batch_size, init_state, beam_size)
         if gen_type not in ('greedy', 'sample'):
-            raise NotImplementedError("gen_type '%s': greedy and sample decoding are built; beam search does not run in "
-                                      "the reference under Python 3 either (decoders.py:289)" % gen_type)
+            raise ValueError("Unsupported decoding mode")            # decoders.py:237
         with torch.no_grad():
             h0 = init_state[0].detach().contiguous()
             sample = gen_type == 'sample'

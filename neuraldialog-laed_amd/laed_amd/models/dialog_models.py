@@ -6,7 +6,7 @@ forward / valid_loss / model_sel_loss semantics and Pack keys as the reference. 
 kernels as DI-VAE / DI-VST; the one new kernel is the attribute-forcing head, which needs
 softmax(dec_outs) @ x_embedding.weight and gets it from laed_softmax_embed_{fwd,bwd} without forming [N,V].
 
-Limits (raise NotImplementedError): decoder attention (use_attn), LSTM cells, fix_batch, beam decoding, data
+Limits (raise NotImplementedError): decoder attention (use_attn), LSTM cells, fix_batch, data
 parallelism for these two models.  valid_loss sums out of place (the reference's AeED mutates loss.nll in place,
 dialog_models.py:280-284).
 """

@@ -183,6 +183,42 @@ def decoder_sample(P, prefix, emb_w, h0, max_len, go_id, eos_id, u):
     return torch.cat(seq, dim=1), lengths.tolist(), h
 
 
+def decoder_beam(P, prefix, emb_w, h0, max_len, go_id, eos_id, beam_size):
+    """DecoderRNN GEN with gen_type='beam', laed/enc2dec/decoders.py:194-202,222-235,270-291, restated with the integer
+    semantics of the torch the reference targets (top_id.div = floor division).  PARITY UNPINNED: the reference's own
+    back-tracking does not run under Python 3 / torch 2 (torch.cat of 0-d tensors at :289), so no golden vector exists.
+    As in the reference the hidden states are NOT reordered by the back pointers.
+    Returns (sequence [B,max_len] int64, lengths list of B*beam)."""
+    B, K = h0.shape[0], beam_size
+    h = h0.repeat(1, K).view(B * K, -1)                                  # repeat_state, base_modules.py:69-71
+    ids = torch.full((B * K, 1), go_id, dtype=torch.int64)
+    V = P[prefix + 'project.weight'].shape[0]
+    cum_sum = None
+    syms, bps = [], []
+    lengths = np.array([max_len] * (B * K))
+    for di in range(max_len):
+        lp, h = decoder_teacher(P, prefix, emb_w, ids, h)
+        step = lp[:, 0]
+        if di == 0:
+            seq_score = step.reshape(B, -1)[:, :V]
+        else:
+            seq_score = (cum_sum + step).reshape(B, -1)
+        top_v, top_id = seq_score.topk(K)
+        bps.append(top_id // V)
+        ids = (top_id % V).reshape(-1, 1)
+        cum_sum = top_v.reshape(-1, 1)
+        syms.append(ids.view(B, K))
+        eos = (ids.view(-1) == eos_id).numpy()
+        lengths[(lengths > di) & eos] = di + 1
+    best = cum_sum.view(B, K).topk(1)[1].view(-1)
+    rows = torch.arange(B)
+    out = torch.zeros(B, max_len, dtype=torch.int64)
+    for di in range(max_len - 1, -1, -1):
+        out[:, di] = syms[di][rows, best]
+        best = bps[di][rows, best]
+    return out, lengths.tolist()
+
+
 # --------------------------------------------------------------------------------------
 # models (functional; P = dict name -> tensor with the reference's state_dict keys)
 # --------------------------------------------------------------------------------------

@@ -229,3 +229,21 @@ def test_latent_analysis_entry_points_vs_reference():
     (seq, _, _), ids = O.divae_exp_enumerate(P, cfg)
     assert np.array_equal(ids.numpy(), G["exp_enumerate/all_y_ids"])
     assert np.array_equal(seq.numpy(), G["exp_enumerate/sequence"])
+
+
+def test_oracle_beam_search_degenerates_to_greedy_and_tracks_back():
+    """oracle.decoder_beam (decoders.py:194-291 restated; PARITY UNPINNED, the reference's back-tracking does not run
+    under Python 3): beam_size = 1 is greedy decoding; every returned sequence is a path through its own back pointers
+    (its first symbol is one of the first step's top-k symbols of that sequence)."""
+    G = load_golden("modules")
+    sd = {k[len("dec/sd/"):]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith("dec/sd/")}
+    P = {"d." + k: v for k, v in sd.items()}
+    h0 = torch.from_numpy(np.random.RandomState(1).randn(5, 9).astype(np.float32))
+    s1, l1 = O.decoder_beam(P, "d.", P["d.embedding.weight"], h0, 6, 2, 3, 1)
+    g, lg, _ = O.decoder_greedy(P, "d.", P["d.embedding.weight"], h0, 6, 2, 3)
+    assert torch.equal(s1, g) and l1 == lg
+    s3, l3 = O.decoder_beam(P, "d.", P["d.embedding.weight"], h0, 6, 2, 3, 3)
+    assert s3.shape == (5, 6) and len(l3) == 15
+    lp0, _ = O.decoder_teacher(P, "d.", P["d.embedding.weight"], torch.full((5, 1), 2, dtype=torch.int64), h0)
+    top3 = lp0[:, 0].topk(3)[1]
+    assert all(int(s3[b, 0]) in top3[b].tolist() for b in range(5))
