@@ -76,6 +76,7 @@ struct SgemmArgs {
     int M, N, K;
     int accumulate, colsum_acc;
     int tiles_m, tiles_n;
+    int group_m;           // row tiles per group of the grouped block order
     int splitk, kper;      // splitk > 1: block `split` covers K range [split*kper, min(K, (split+1)*kper)) and writes
     float* ws;             //   its raw partial tile to ws[split][M][N] (colsum partials to ws_colsum[split][M])
     float* ws_colsum;
@@ -218,7 +219,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     if (p.splitk > 1) { split = wg % p.splitk; wg /= p.splitk; }
     const int kbeg = split * p.kper;
     const int kend = (p.splitk > 1) ? min(p.K, kbeg + p.kper) : p.K;
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = p.group_m;
     int in_group = GROUP_M * p.tiles_n;
     int gid = wg / in_group, first_m = gid * GROUP_M;
     int gsz = min(p.tiles_m - first_m, GROUP_M);
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void sgemm_glds_kernel(SgemmArgs p) {
     if (p.splitk > 1) { split = wg % p.splitk; wg /= p.splitk; }
     const int kbeg = split * p.kper;
     const int kend = (p.splitk > 1) ? min(p.K, kbeg + p.kper) : p.K;
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = p.group_m;
     int in_group = GROUP_M * p.tiles_n;
     int gid = wg / in_group, first_m = gid * GROUP_M;
     int gsz = min(p.tiles_m - first_m, GROUP_M);
@@ -723,6 +724,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs p) {
     }
 }
 
+// Row tiles per group of the grouped block order (blocks of a group run together on one XCD and share operand strips
+// through its L2).  LAED_GEMM_GROUP_M overrides it in the hooks build.
+int group_m_for(int tiles_m, int tiles_n) {
+    (void)tiles_m; (void)tiles_n;
+    static const int forced = []() { const char* e = laed_exp_hook("LAED_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+    return forced > 0 ? forced : 8;
+}
+
 template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0>
 int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
@@ -737,6 +746,7 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     SgemmArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
+    p.group_m = group_m_for(p.tiles_m, p.tiles_n);
     int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
     ProfRec r;
@@ -767,6 +777,7 @@ int launch_glds(const SgemmArgs& a, hipStream_t stream) {
     SgemmArgs p = a;
     p.tiles_m = (a.M + 127) / 128;
     p.tiles_n = (a.N + 127) / 128;
+    p.group_m = group_m_for(p.tiles_m, p.tiles_n);
     int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
     ProfRec r;
@@ -965,7 +976,7 @@ static int sgemm_dispatch(bool transA, bool transB, int M, int N, int K,
     a.M = M; a.N = N; a.K = K;
     a.accumulate = accumulate ? 1 : 0;
     a.colsum_acc = colsum_accumulate ? 1 : 0;
-    a.tiles_m = a.tiles_n = 0;
+    a.tiles_m = a.tiles_n = 0; a.group_m = 8;
     a.splitk = 1; a.kper = 0; a.ws = ws; a.ws_colsum = nullptr;
     a.labels = nullptr; a.part = nullptr; a.lab_logit = nullptr;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
@@ -985,7 +996,7 @@ int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t l
     a.lda = lda; a.ldb = ldb; a.ldc = 0;
     a.M = M; a.N = N; a.K = K;
     a.accumulate = 0; a.colsum_acc = 0;
-    a.tiles_m = a.tiles_n = 0;
+    a.tiles_m = a.tiles_n = 0; a.group_m = 8;
     a.splitk = 1; a.kper = ((K + BK - 1) / BK) * BK; a.ws = nullptr; a.ws_colsum = nullptr;
     a.labels = labels; a.part = part; a.lab_logit = lab_logit;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
