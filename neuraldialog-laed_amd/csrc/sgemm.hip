@@ -699,6 +699,161 @@ __global__ __launch_bounds__(512, 2) void sgemm_glds_kernel(SgemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (hooks build only, LAED_GEMM_GLDS=2): the LDS-DMA kernel with a LOADER WAVE.  Eight compute waves execute
+// nothing but LDS fragment reads, MFMAs and the barrier -- no VMEM instruction and no vmcnt wait ever enters their
+// instruction streams -- and a ninth wave issues every DMA of the block (16 per 16-deep sub-tile: 8 one-KiB pieces per
+// operand) three sub-tiles ahead, waits on the counted vmcnt and joins the same barrier.  This separates "a wave that
+// issues loads loses MFMA issue" from "the loads' latency reaches the barrier".
+template <bool TA, bool TB>
+__global__ __launch_bounds__(576, 2) void sgemm_gldsw_kernel(SgemmArgs p) {
+    constexpr int BM = 128, BN = 128, NTC = 512, WGM = 2, WGN = 4, TM = 2, TN = 1;
+    constexpr int KS = 16, NST = 4;
+    constexpr bool AK = !TA, BKC = TB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    int nwg = gridDim.x, pid = blockIdx.x;
+    int xcd = pid & 7, q = nwg >> 3, r = nwg & 7;
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+    int split = 0;
+    if (p.splitk > 1) { split = wg % p.splitk; wg /= p.splitk; }
+    const int kbeg = split * p.kper;
+    const int kend = (p.splitk > 1) ? min(p.K, kbeg + p.kper) : p.K;
+    const int GROUP_M = p.group_m;
+    int in_group = GROUP_M * p.tiles_n;
+    int gid = wg / in_group, first_m = gid * GROUP_M;
+    int gsz = min(p.tiles_m - first_m, GROUP_M);
+    int tile_m = first_m + (wg % in_group) % gsz;
+    int tile_n = (wg % in_group) / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int klen = kend - kbeg;
+    if (!((m0 + BM <= p.M) && (n0 + BN <= p.N) && klen >= KS * NST && (klen % KS) == 0)) {     // block-uniform
+        if (wave >= NTC / 64) return;              // the loader wave has no part in the register-staged body
+        sgemm_block<BM, BN, TA, TB, true, NTC, 0>(p);
+        return;
+    }
+    float* imgA = smem;                         // [NST][BM * KS]
+    float* imgB = smem + NST * BM * KS;         // [NST][BN * KS]
+    const int nsub = klen / KS;
+
+    if (wave == NTC / 64) {
+        // ---- loader wave: piece w of an operand's sub-tile image = rows 16w.. (K-contiguous) or k-rows 2w, 2w+1
+        const float* pa;
+        const float* pb;
+        int64_t pa_t, pb_t, pa_w, pb_w;
+        if (AK) {
+            const int row = lane >> 2, qs = (lane & 3) ^ ((row >> 2) & 3);        // (16w + row) >> 2 & 3 == row >> 2 & 3
+            pa = p.A + (int64_t)(m0 + row) * p.lda + kbeg + 4 * qs; pa_t = KS; pa_w = (int64_t)16 * p.lda;
+        } else {
+            pa = p.A + (int64_t)(kbeg + (lane >> 5)) * p.lda + m0 + 4 * (lane & 31); pa_t = (int64_t)KS * p.lda; pa_w = (int64_t)2 * p.lda;
+        }
+        if (BKC) {
+            const int row = lane >> 2, qs = (lane & 3) ^ ((row >> 2) & 3);
+            pb = p.B + (int64_t)(n0 + row) * p.ldb + kbeg + 4 * qs; pb_t = KS; pb_w = (int64_t)16 * p.ldb;
+        } else {
+            pb = p.B + (int64_t)(kbeg + (lane >> 5)) * p.ldb + n0 + 4 * (lane & 31); pb_t = (int64_t)KS * p.ldb; pb_w = (int64_t)2 * p.ldb;
+        }
+        auto issue = [&](int stage, bool advance) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                __builtin_amdgcn_global_load_lds(LAED_GPTR(pa + w * pa_w), LAED_LPTR(imgA + stage * BM * KS + w * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(LAED_GPTR(pb + w * pb_w), LAED_LPTR(imgB + stage * BN * KS + w * 256), 16, 0, 0);
+            }
+            if (advance) { pa += pa_t; pb += pb_t; }
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_) issue(s_, s_ + 1 < nsub);
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");           // sub-tile 0 landed (1, 2 in flight)
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nsub; ++t) {
+            issue((t + NST - 1) & (NST - 1), t + NST < nsub);        // sub-tile t+3 (or a harmless re-load of the last one)
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");       // sub-tile t+1 landed (t+2, t+3 in flight)
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- compute waves
+    const int wm = wave / WGN, wn = wave % WGN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
+    const int arow = wm * (BM / WGM) + lrow, brow = wn * (BN / WGN) + lrow;
+    const int fsw = (lrow >> 2) & 3;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        aoff[g] = AK ? arow * KS + 4 * ((2 * g + lk) ^ fsw) : (4 * (2 * g + lk)) * BM + arow;
+        boff[g] = BKC ? brow * KS + 4 * ((2 * g + lk) ^ fsw) : (4 * (2 * g + lk)) * BN + brow;
+    }
+    const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
+    const bool csum_wave = do_colsum && wn == 0;
+    float fsum[TM] = {0.f, 0.f};
+    __builtin_amdgcn_s_barrier();                                    // sub-tile 0 is in LDS
+    asm volatile("" ::: "memory");
+    for (int t = 0; t < nsub; ++t) {
+        const float* a_s = imgA + (t & (NST - 1)) * BM * KS;
+        const float* b_s = imgB + (t & (NST - 1)) * BN * KS;
+        float fa[2][TM][4], fb[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (AK) {
+                    const float4 v = *reinterpret_cast<const float4*>(a_s + aoff[g] + i * 32 * KS);
+                    fa[g][i][0] = v.x; fa[g][i][1] = v.y; fa[g][i][2] = v.z; fa[g][i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[g][i][j] = a_s[aoff[g] + j * BM + i * 32];
+                }
+            }
+            if (BKC) {
+                const float4 v = *reinterpret_cast<const float4*>(b_s + boff[g]);
+                fb[g][0] = v.x; fb[g][1] = v.y; fb[g][2] = v.z; fb[g][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[g][j] = b_s[boff[g] + j * BN];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][i][j], fb[g][j], acc[i][0], 0, 0, 0);
+        if (TA && csum_wave) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fsum[i] += fa[g][i][j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
+    if (TA && csum_wave) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s_ = fsum[i] + __shfl_xor(fsum[i], 32, 64);
+            if (lk == 0) {
+                const int m = m0 + wm * (BM / WGM) + i * 32 + lrow;
+                if (p.splitk > 1) p.ws_colsum[(int64_t)split * p.M + m] = s_;
+                else p.colsum[m] = p.colsum_acc ? p.colsum[m] + s_ : s_;
+            }
+        }
+    }
+}
+
 #endif   // LAED_ENV_HOOKS
 
 // C = sum_s ws[s] (+ bias) (+ C); colsum = sum_s ws_colsum[s] (+ colsum).  Fixed summation order: reproducible.
@@ -762,13 +917,14 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
 }
 
 #ifdef LAED_ENV_HOOKS
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool LW = false>
 int launch_glds(const SgemmArgs& a, hipStream_t stream) {
     constexpr size_t lds_glds = (size_t)4 * 2 * 128 * 16 * sizeof(float);
     constexpr int SA = 128 + (!TA ? 1 : 4), SB = 128 + (TB ? 1 : 4);
     constexpr size_t lds_reg = (size_t)2 * BK * (SA + SB) * sizeof(float);      // edge blocks: the register-staged body
     constexpr size_t lds = lds_glds > lds_reg ? lds_glds : lds_reg;
-    auto kern = sgemm_glds_kernel<TA, TB>;
+    auto kern = LW ? sgemm_gldsw_kernel<TA, TB> : sgemm_glds_kernel<TA, TB>;
+    constexpr int nthreads = LW ? 576 : 512;
     static uint64_t attr_set = 0;
     if (laed_first_use_on_device(&attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -782,17 +938,17 @@ int launch_glds(const SgemmArgs& a, hipStream_t stream) {
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
     ProfRec r;
     if (g_prof_on.load(std::memory_order_relaxed) && prof_begin(r, 2.0 * a.M * a.N * a.K, (TA ? 2 : (TB ? 0 : 1)) * 2, stream)) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nthreads), lds, stream, p);
         prof_end(r, stream);
     } else {
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nthreads), lds, stream, p);
     }
     LAED_LAUNCH_CHECK("sgemm_glds");
     return 0;
 }
 
-bool glds_on() {
-    static const bool v = []() { const char* e = laed_exp_hook("LAED_GEMM_GLDS"); return e != nullptr && atoi(e) == 1; }();
+int glds_mode() {       // 0 off, 1 LDS-DMA kernel, 2 LDS-DMA kernel with a loader wave
+    static const int v = []() { const char* e = laed_exp_hook("LAED_GEMM_GLDS"); return e != nullptr ? atoi(e) : 0; }();
     return v;
 }
 #endif
@@ -893,7 +1049,8 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
         st = launch_cfg<256, 256, TA, TB, true, 1024>(a, stream);      // experiment: 16 waves, 256x256 tile, one block per CU
 #endif
 #ifdef LAED_ENV_HOOKS
-    else if (big && vec && glds_on() && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB>(a, stream);
+    else if (big && vec && glds_mode() == 1 && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB>(a, stream);
+    else if (big && vec && glds_mode() == 2 && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB, true>(a, stream);
 #endif
     else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
     else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
