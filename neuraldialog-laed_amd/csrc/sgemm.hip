@@ -86,6 +86,9 @@ struct SgemmArgs {
     float* lab_logit;      //   lab_logit[m] = logit[m][labels[m]] (written by the one lane that holds it)
 };
 
+#ifndef SGEMM_BK16_WAVES
+#define SGEMM_BK16_WAVES 2      // minimum waves per SIMD asked of the compiler for the 16-deep instantiations
+#endif
 #ifndef SGEMM_BK
 #define SGEMM_BK 32
 #endif
@@ -94,9 +97,10 @@ constexpr int BK = SGEMM_BK;   // K tile depth (16 measured in round 2: more blo
 // Load a (BR rows) x (BK k) tile into registers as float4s.
 //  KCONTIG: element (r,k) at P[r*ld + k]   -> each thread takes 4 consecutive k of one row
 // !KCONTIG: element (r,k) at P[k*ld + r]   -> each thread takes 4 consecutive rows of one k
-template <bool KCONTIG, int BR, bool VEC, int NT>
+template <bool KCONTIG, int BR, bool VEC, int NT, int BKT = BK>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t ld, int r0, int k0, int R, int K,
-                                          int tid, float4 (&reg)[BR * BK / 4 / NT]) {
+                                          int tid, float4 (&reg)[BR * BKT / 4 / NT]) {
+    constexpr int BK = BKT;
     constexpr int NL = BR * BK / 4 / NT;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -137,8 +141,9 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t l
 
 // Write the registers to the LDS image s[BK][S], S = BR + pad (pad 1 for KCONTIG: conflict-free transposing
 // b32 writes; pad 4 otherwise: 16-byte aligned b128 writes).
-template <bool KCONTIG, int BR, int NT>
-__device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const float4 (&reg)[BR * BK / 4 / NT]) {
+template <bool KCONTIG, int BR, int NT, int BKT = BK>
+__device__ __forceinline__ void tile_store(float* __restrict__ s, int tid, const float4 (&reg)[BR * BKT / 4 / NT]) {
+    constexpr int BK = BKT;
     constexpr int NL = BR * BK / 4 / NT;
     constexpr int S = BR + (KCONTIG ? 1 : 4);
 #pragma unroll
@@ -186,8 +191,9 @@ __device__ __forceinline__ void store_acc(const SgemmArgs& p, const f32x16 (&acc
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0, int BKT = BK>
 __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
+    constexpr int BK = BKT;    // K tile depth of THIS instantiation (the file-scope BK stays the host side's K granule)
     constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
     constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
     constexpr int SA = BM + (AK ? 1 : 4);
@@ -297,8 +303,8 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
 #pragma unroll
         for (int u = 0; u < NL; ++u) load_unit(u);
     } else {
-        tile_load<AK, BM, VEC, NT>(p.A, p.lda, m0, kbeg, p.M, kend, tid, ra);
-        tile_load<BKC, BN, VEC, NT>(p.B, p.ldb, n0, kbeg, p.N, kend, tid, rb);
+        tile_load<AK, BM, VEC, NT, BK>(p.A, p.lda, m0, kbeg, p.M, kend, tid, ra);
+        tile_load<BKC, BN, VEC, NT, BK>(p.B, p.ldb, n0, kbeg, p.N, kend, tid, rb);
     }
     add_colsum();
 #pragma unroll
@@ -397,8 +403,8 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     for (; kt < nkt; ++kt) {
         const bool more = (kt + 1 < nkt);
         if (more) {
-            tile_load<AK, BM, VEC, NT>(p.A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, kend, tid, ra);
-            tile_load<BKC, BN, VEC, NT>(p.B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, kend, tid, rb);
+            tile_load<AK, BM, VEC, NT, BK>(p.A, p.lda, m0, kbeg + (kt + 1) * BK, p.M, kend, tid, ra);
+            tile_load<BKC, BN, VEC, NT, BK>(p.B, p.ldb, n0, kbeg + (kt + 1) * BK, p.N, kend, tid, rb);
         }
         const float* a_s = a_base + cur * BK * SA;
         const float* b_s = b_base + cur * BK * SB;
@@ -417,8 +423,8 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         }
         if (more) {
             add_colsum();
-            tile_store<AK, BM, NT>(sA + (cur ^ 1) * BK * SA, tid, ra);
-            tile_store<BKC, BN, NT>(sB + (cur ^ 1) * BK * SB, tid, rb);
+            tile_store<AK, BM, NT, BK>(sA + (cur ^ 1) * BK * SA, tid, ra);
+            tile_store<BKC, BN, NT, BK>(sB + (cur ^ 1) * BK * SB, tid, rb);
         }
         __syncthreads();
         cur ^= 1;
@@ -505,9 +511,9 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0>
-__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) void sgemm_kernel(SgemmArgs p) {
-    sgemm_block<BM, BN, TA, TB, VEC, NT, EPI>(p);
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0, int BKT = BK>
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : (BKT == 16 && NT == 512 ? SGEMM_BK16_WAVES : 2))) void sgemm_kernel(SgemmArgs p) {
+    sgemm_block<BM, BN, TA, TB, VEC, NT, EPI, BKT>(p);
 }
 
 #ifdef LAED_ENV_HOOKS
@@ -887,11 +893,14 @@ int group_m_for(int tiles_m, int tiles_n) {
     return forced > 0 ? forced : 8;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0, int BKT = BK>
 int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
-    constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
-    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT, EPI>;
+    constexpr size_t lds_tiles = (size_t)2 * BKT * (SA + SB) * sizeof(float);
+    // the epilogues reuse the tile memory: online-softmax partials [NT/128][BM][2], column sums [NT/(BM/4)][BM/4][4]
+    constexpr size_t lds_epi = (size_t)(EPI == 1 ? (NT / 128) * BM * 2 : (TA ? NT * 4 : 0)) * sizeof(float);
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
+    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT, EPI, BKT>;
     static uint64_t attr_set = 0;   // per device
     if (laed_first_use_on_device(&attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -952,6 +961,11 @@ int glds_mode() {       // 0 off, 1 LDS-DMA kernel, 2 LDS-DMA kernel with a load
     return v;
 }
 #endif
+
+bool bk16_on() {        // LAED_GEMM_BK16=0 (hooks build) keeps the 32-deep K tile everywhere
+    static const bool v = []() { const char* e = laed_exp_hook("LAED_GEMM_BK16"); return !(e != nullptr && atoi(e) == 0); }();
+    return v;
+}
 
 template <bool TA, bool TB>
 int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, int* splits_out, int force_split,
@@ -1052,6 +1066,10 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     else if (big && vec && glds_mode() == 1 && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB>(a, stream);
     else if (big && vec && glds_mode() == 2 && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB, true>(a, stream);
 #endif
+    // K tile depth of the 8-wave 128x128 kernel: 16 for the x W^T and x W layouts (33 KB of LDS and fewer staging
+    // registers: three blocks per CU instead of two; logits +2 %, dh +1.3 % at the projection shapes), 32 for A^T B
+    // (dW: -1.3 % with 16; both of its operands are read with b32 fragment loads) -- tools/gemm_exp.py, DESIGN.md section 4
+    else if (big && vec && big_tile_threads() == 512 && !TA && bk16_on()) st = launch_cfg<128, 128, TA, TB, true, 512, 0, 16>(a, stream);
     else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
     else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
     else st = vec ? launch_cfg<64, 64, TA, TB, true>(a, stream) : launch_cfg<64, 64, TA, TB, false>(a, stream);

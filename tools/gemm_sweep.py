@@ -19,6 +19,11 @@ SHAPES = [("logits NT  P", 1170, 10004, 512, "NT"), ("logits NT  VST", 2340, 100
           ("dW_ih TN   P", 1536, 200, 1200, "TN"), ("dx NN      VST", 2400, 200, 1536, "NN")]
 
 
+# the recurrence's per-timestep backward product dh = dgh W_hh at the S shape (H = 1024), per-GPU batches of 8/4/2 ranks
+RECUR = [("dh_rec NN B=512", 512, 1024, 3072, "NN"), ("dh_rec NN B=1024", 1024, 1024, 3072, "NN"),
+         ("dh_rec NN B=2048", 2048, 1024, 3072, "NN")]
+
+
 def child(M, N, K, lay):
     import torch
     from laed_amd import ops
@@ -43,7 +48,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
         sys.exit(0)
-    for name, M, N, K, lay in SHAPES:
+    for name, M, N, K, lay in (RECUR if "--recur" in sys.argv else SHAPES):
         res = {}
         forces = [] if "--heuristic-only" in sys.argv else ["%d,%d" % (t, s) for t in (64, 128) for s in (1, 2, 3, 4, 6, 8, 12, 16)]
         for force in [None] + forces:
