@@ -37,7 +37,10 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(70, 50, 33), (128, 128, 32), (300, 200, 129), (1170, 1000, 512), (2048, 2304, 200),
-                                   (1, 7, 5), (33, 1, 64)])
+                                   (1, 7, 5), (33, 1, 64),
+                                   # > 1024 tiles of 128x128: the 8-wave kernels (16-deep K tile for x W^T / x W, 32-deep
+                                   # for A^T B) with edge tiles and a K tail that is a multiple of neither depth
+                                   (4100, 4100, 1028)])
 def test_sgemm_layouts(ops, M, N, K):
     for (tA, tB) in ((False, True), (False, False), (True, False)):
         A = rnd(K, M, seed=1) if tA else rnd(M, K, seed=1)
