@@ -224,7 +224,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
                                     timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            # gloo announces its connections on stdout: keep the one-JSON-line contract by sending fd 1 to stderr meanwhile
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
         parallel.init()
 
     from laed_amd import ops as _ops

@@ -332,9 +332,8 @@ _CU_SHARE = {"streams": 1, "processes": 1}
 def set_device_sharers(n):
     """Tell the engine that `n` processes run on THIS GPU (a rehearsal of the multi-rank path on fewer GPUs than
     ranks; production is one process per GPU, n = 1).  The persistent small-batch GRU kernels need their whole grid
-    resident at once and cannot see another process's grid, so each process then only counts on 1/n of the CUs --
-    two 256-workgroup grids of two processes on one GPU would otherwise wait for each other until their bounded polls
-    give up (seconds per launch, NaN outputs)."""
+    resident at once, which nothing guarantees beside another process's work: with n > 1 every recurrence runs as
+    per-step launches (see _cu_budget)."""
     _CU_SHARE["processes"] = max(1, int(n))
 
 
@@ -358,7 +357,15 @@ class concurrent_streams(object):
 
 
 def _cu_budget(device):
-    n = _CU_SHARE["streams"] * _CU_SHARE["processes"]
+    if _CU_SHARE["processes"] > 1:
+        # Another PROCESS on this GPU: co-residency of a persistent grid cannot be counted on at all.  The hardware
+        # scheduler time-slices the processes' queues (waves are saved and restored), so a grid that spins on its own
+        # counters keeps being switched out under the spin: measured with two ranks on one MI355X (bench.py --backend
+        # gloo, B = 64 per rank, H = 1024: the 128-workgroup backward grid fits half the CUs) single 64x64 GEMM launches
+        # took up to 1 s and steps 0.1 .. 18 s -- results correct, no poll timed out.  A budget of one CU sends every
+        # recurrence to the per-step launches (82 ms per step in the same rehearsal).
+        return 1
+    n = _CU_SHARE["streams"]
     if n <= 1:
         return 0                                            # the whole device
     return max(1, torch.cuda.get_device_properties(device).multi_processor_count // n)
