@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const int q_ = ks * 3 + g;
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1], bf[ks & 1][g], acc[g], 0, 0, 0);
+                    laed_mfma_32x32x2(acc[g], af[ks & 1], bf[ks & 1][g]);          // accumulators in AccVGPRs (laed_common.h)
                     if (g == 0 && ks + 1 < KS) {
 #if !defined(GRU_EXP) || !(GRU_EXP & 4)
                         const int o = 2 * (ks + 1) * WK;
@@ -235,15 +235,16 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
             const int krow = 2 * (wq + ks * WK) + lk;
             float a = h_s[krow * SH];
             float b0 = w_s[krow * SW], b1 = w_s[krow * SW + UB], b2 = w_s[krow * SW + 2 * UB];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+            laed_mfma_32x32x2(acc[0], a, b0);
+            laed_mfma_32x32x2(acc[1], a, b1);
+            laed_mfma_32x32x2(acc[2], a, b2);
         }
         if (more) store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
+    laed_mfma_drain();
     if (WK > 1) {   // every wave hands the rows it does not own to their owners (fixed summation order: wq ascending)
         float* red = smem;   // all waves are past the last barrier: tiles are dead
         float* d = red + ((wq * WM * WU + wu * WM + wm) * 48) * 64 + lane;

@@ -11,6 +11,20 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// acc += a (x) b with v_mfma_f32_32x32x2_f32 and the accumulator tile held in AccVGPRs.  Left to itself the compiler
+// keeps MFMA accumulators in ArchVGPRs whenever the register budget allows ("VGPR form"); there the MFMA's C/D traffic
+// shares the register-file ports with the returning global / LDS loads of the staging pipeline.  With the tiles in
+// AccVGPRs the fp32 GEMM gained 2 % over all products and 3.7 % on the dW product (S-fixed step 439.5 -> 431.2 ms, same
+// bits).  The constraint "a" is the only way to ask for that form, hence inline asm; the asm is
+// opaque to the compiler's MFMA hazard recognizer, so every reader of `acc` that is not another such MFMA on the same
+// tile must be preceded by laed_mfma_drain() (XDL write -> VALU / v_accvgpr_read needs 18 wait states after a 16-pass op).
+__device__ __forceinline__ void laed_mfma_32x32x2(f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void laed_mfma_drain() {
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+}
+
 char* laed_err_buf();   // thread-local, 256 bytes (laed_api.hip)
 
 static inline int laed_fail(int code, const char* fmt, ...) {

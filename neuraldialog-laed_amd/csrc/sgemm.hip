@@ -349,7 +349,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int q_ = kk * NMF + i * TN + j;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk % 3][i], bf[kk % 3][j], acc[i][j], 0, 0, 0);
+                        laed_mfma_32x32x2(acc[i][j], af[kk % 3][i], bf[kk % 3][j]);
 #if !defined(SGEMM_EXP) || !(SGEMM_EXP & 4)
                         if (i * TN + j == 0 && kk + 2 < BK / 2) {        // fragments of the k pair after the next
 #pragma unroll
@@ -419,7 +419,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    laed_mfma_32x32x2(acc[i][j], a[i], b[j]);
         }
         if (more) {
             add_colsum();
@@ -429,6 +429,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         __syncthreads();
         cur ^= 1;
     }
+    laed_mfma_drain();        // the accumulators are read (v_accvgpr_read) from here on
 
     if (EPI == 1) {
         // ---- online-softmax epilogue: per row of the block tile, (max, sum exp) over its BN columns and the label's
