@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void sgemm_glds_kernel(SgemmArgs p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[g][i][j], f.b[g][j], acc[i][0], 0, 0, 0);
+                laed_mfma_32x32x2(acc[i][0], f.a[g][i][j], f.b[g][j]);
         if (TA && csum_wave) {                      // wave-uniform: column sums of A from this wave's own fragments
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -692,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void sgemm_glds_kernel(SgemmArgs p) {
     if (t < nsub) step(t, f0, f1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing re-loads must not outlive the block
 
+    laed_mfma_drain();
     store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
     if (TA && csum_wave) {
 #pragma unroll
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(576, 2) void sgemm_gldsw_kernel(SgemmArgs p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][i][j], fb[g][j], acc[i][0], 0, 0, 0);
+                    laed_mfma_32x32x2(acc[i][0], fa[g][i][j], fb[g][j]);
         if (TA && csum_wave) {
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -847,6 +848,7 @@ __global__ __launch_bounds__(576, 2) void sgemm_gldsw_kernel(SgemmArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    laed_mfma_drain();
     store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
     if (TA && csum_wave) {
 #pragma unroll
