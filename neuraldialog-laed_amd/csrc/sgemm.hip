@@ -1069,9 +1069,10 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     else if (big && vec && glds_mode() == 1 && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB>(a, stream);
     else if (big && vec && glds_mode() == 2 && a.K % 16 == 0 && big_tile_threads() == 512) st = launch_glds<TA, TB, true>(a, stream);
 #endif
-    // K tile depth of the 8-wave 128x128 kernel: 16 for the x W^T and x W layouts (33 KB of LDS and fewer staging
-    // registers: three blocks per CU instead of two; logits +2 %, dh +1.3 % at the projection shapes), 32 for A^T B
-    // (dW: -1.3 % with 16; both of its operands are read with b32 fragment loads) -- tools/gemm_exp.py, DESIGN.md section 4
+    // K tile depth of the 8-wave 128x128 kernel: 16 for the x W^T and x W layouts (logits +2 %, dh +1.3 % at the
+    // projection shapes: a shorter prologue and a finer interleave of staging and MFMAs -- still two blocks per CU, and
+    // forcing three with __launch_bounds__(512, 6) is slower), 32 for A^T B (dW: -1.3 % with 16 in the compiler's VGPR
+    // form, +-0 with AccVGPR accumulators) -- tools/gemm_exp.py, DESIGN.md section 4
     else if (big && vec && big_tile_threads() == 512 && !TA && bk16_on()) st = launch_cfg<128, 128, TA, TB, true, 512, 0, 16>(a, stream);
     else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
     else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
