@@ -191,8 +191,9 @@ __device__ __forceinline__ void store_acc(const SgemmArgs& p, const f32x16 (&acc
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0, int BKT = BK>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0, int BKT = BK, int PF = 1>
 __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
+    constexpr int SGEMM_PF2 = PF == 2 ? 1 : 0;   // PF = 2: the scheduled loop keeps TWO K tiles in flight in registers
     constexpr int BK = BKT;    // K tile depth of THIS instantiation (the file-scope BK stays the host side's K granule)
     constexpr bool AK = !TA;   // A is K-contiguous when not transposed ([M][K])
     constexpr bool BKC = TB;   // B is K-contiguous when transposed   ([N][K])
@@ -242,6 +243,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[NLA], rb[NLB];
+    float4 ra2[NLA], rb2[NLB];       // second staging set (PF = 2): the scheduled loop prefetches TWO K tiles ahead
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_colsum = TA && (p.colsum != nullptr) && (tile_n == 0);
     const int lrow = lane & 31, lk = lane >> 5;
@@ -249,9 +251,14 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     const float* a_base = sA + wm * (BM / WGM) + lrow + lk * SA;   // fragment row (2*kk + lk) folded into the base
     const float* b_base = sB + wn * (BN / WGN) + lrow + lk * SB;
 
-    auto add_colsum = [&]() {
+    auto add_colsum = [&](int set = 0) {
         if (TA && do_colsum) {
             asm volatile("; colsum" ::: "memory");     // keeps this a (scalar) branch: 7 of 8 blocks skip the adds
+            if (SGEMM_PF2 && set) {
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) { csum.x += ra2[i].x; csum.y += ra2[i].y; csum.z += ra2[i].z; csum.w += ra2[i].w; }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NLA; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
         }
@@ -281,19 +288,26 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     // one store "unit" = one float4 register; per-thread LDS offset + compile-time unit offsets
     const int sa_off = AK ? (4 * (tid % (BK / 4))) * SA + tid / (BK / 4) : (tid / (BM / 4)) * SA + 4 * (tid % (BM / 4));
     const int sb_off = BKC ? (4 * (tid % (BK / 4))) * SB + tid / (BK / 4) : (tid / (BN / 4)) * SB + 4 * (tid % (BN / 4));
-    auto store_unit = [&](int u, int buf) {
+    auto store_unit = [&](int u, int buf, int set = 0) {
         if (u < NLA) {
+            const float4 x = (SGEMM_PF2 && set) ? ra2[u] : ra[u];
             float* d = sA + buf * BK * SA + sa_off + (AK ? u * (NT / (BK / 4)) : u * (NT / (BM / 4)) * SA);
-            if (AK) { d[0] = ra[u].x; d[SA] = ra[u].y; d[2 * SA] = ra[u].z; d[3 * SA] = ra[u].w; }
-            else *reinterpret_cast<float4*>(d) = ra[u];
+            if (AK) { d[0] = x.x; d[SA] = x.y; d[2 * SA] = x.z; d[3 * SA] = x.w; }
+            else *reinterpret_cast<float4*>(d) = x;
         } else {
             const int v = u - NLA;
+            const float4 x = (SGEMM_PF2 && set) ? rb2[v] : rb[v];
             float* d = sB + buf * BK * SB + sb_off + (BKC ? v * (NT / (BK / 4)) : v * (NT / (BN / 4)) * SB);
-            if (BKC) { d[0] = rb[v].x; d[SB] = rb[v].y; d[2 * SB] = rb[v].z; d[3 * SB] = rb[v].w; }
-            else *reinterpret_cast<float4*>(d) = rb[v];
+            if (BKC) { d[0] = x.x; d[SB] = x.y; d[2 * SB] = x.z; d[3 * SB] = x.w; }
+            else *reinterpret_cast<float4*>(d) = x;
         }
     };
-    auto load_unit = [&](int u) {
+    auto load_unit = [&](int u, int set = 0) {
+        if (SGEMM_PF2 && set) {
+            if (u < NLA) ra2[u] = *reinterpret_cast<const float4*>(ga + u * a_ist);
+            else rb2[u - NLA] = *reinterpret_cast<const float4*>(gb + (u - NLA) * b_ist);
+            return;
+        }
         if (u < NLA) ra[u] = *reinterpret_cast<const float4*>(ga + u * a_ist);
         else rb[u - NLA] = *reinterpret_cast<const float4*>(gb + (u - NLA) * b_ist);
     };
@@ -321,8 +335,18 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         // re-reads tile kt+1 (cache hit, result unused) instead of branching.
         ga += a_step;
         gb += b_step;
+        if (SGEMM_PF2) {
+            // prefetch distance = TWO K tiles: tile kt+1 sits in register set (kt+1)&1, tile kt+2 in the other one; while
+            // tile kt computes, set (kt+1)&1 goes to LDS[cur^1] and is refilled with tile kt+3
 #pragma unroll
-        for (int u = 0; u < NL; ++u) load_unit(u);
+            for (int u = 0; u < NL; ++u) load_unit(u, 1);
+            if (2 < nfull) { ga += a_step; gb += b_step; }
+#pragma unroll
+            for (int u = 0; u < NL; ++u) load_unit(u, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) load_unit(u);
+        }
         // one K tile out of LDS buffer CUR (compile-time, so that every LDS offset of the body is an immediate)
         auto tile_body = [&](auto cur_c, bool advance) {
             constexpr int CUR = decltype(cur_c)::value;
@@ -368,16 +392,16 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
                         for (int u = 0; u < NL; ++u) {
                             const int gs = Q / 8 + (u * (3 * Q / 4)) / NL;               // store gap of unit u
                             if (q_ == gs) {
-                                if (u == 0) add_colsum();
+                                if (u == 0) add_colsum(SGEMM_PF2 ? (CUR ^ 1) : 0);
 #if defined(SGEMM_EXP) && (SGEMM_EXP & 8)
                                 if (u < NLA) asm volatile("" :: "v"(ra[u].x), "v"(ra[u].y), "v"(ra[u].z), "v"(ra[u].w));
                                 else asm volatile("" :: "v"(rb[u - NLA].x), "v"(rb[u - NLA].y), "v"(rb[u - NLA].z), "v"(rb[u - NLA].w));
 #else
-                                store_unit(u, CUR ^ 1);                                  // tile kt+1 -> LDS
+                                store_unit(u, CUR ^ 1, SGEMM_PF2 ? (CUR ^ 1) : 0);       // tile kt+1 -> LDS
 #endif
                             }
 #if !defined(SGEMM_EXP) || !(SGEMM_EXP & 16)
-                            if (q_ == gs + 1) load_unit(u);                              // tile kt+2 -> registers
+                            if (q_ == gs + 1) load_unit(u, SGEMM_PF2 ? (CUR ^ 1) : 0);   // tile kt+2 (kt+3 with two sets) -> registers
 #endif
                         }
 #endif
@@ -390,8 +414,8 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
 #endif
         };
         for (; kt + 2 < nfull; kt += 2) {           // cur == 0 here
-            tile_body(std::integral_constant<int, 0>(), true);
-            tile_body(std::integral_constant<int, 1>(), kt + 3 < nfull);
+            tile_body(std::integral_constant<int, 0>(), kt + 2 + SGEMM_PF2 < nfull);
+            tile_body(std::integral_constant<int, 1>(), kt + 3 + SGEMM_PF2 < nfull);
         }
         if (kt + 1 < nfull) {
             tile_body(std::integral_constant<int, 0>(), false);
@@ -512,9 +536,9 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0, int BKT = BK>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT, int EPI = 0, int BKT = BK, int PF = 1>
 __global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : (BKT == 16 && NT == 512 ? SGEMM_BK16_WAVES : 2))) void sgemm_kernel(SgemmArgs p) {
-    sgemm_block<BM, BN, TA, TB, VEC, NT, EPI, BKT>(p);
+    sgemm_block<BM, BN, TA, TB, VEC, NT, EPI, BKT, PF>(p);
 }
 
 #ifdef LAED_ENV_HOOKS
@@ -896,14 +920,14 @@ int group_m_for(int tiles_m, int tiles_n) {
     return forced > 0 ? forced : 8;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0, int BKT = BK>
+template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0, int BKT = BK, int PF = 1>
 int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
     constexpr size_t lds_tiles = (size_t)2 * BKT * (SA + SB) * sizeof(float);
     // the epilogues reuse the tile memory: online-softmax partials [NT/128][BM][2], column sums [NT/(BM/4)][BM/4][4]
     constexpr size_t lds_epi = (size_t)(EPI == 1 ? (NT / 128) * BM * 2 : (TA ? NT * 4 : 0)) * sizeof(float);
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
-    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT, EPI, BKT>;
+    auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT, EPI, BKT, PF>;
     static uint64_t attr_set = 0;   // per device
     if (laed_first_use_on_device(&attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1073,6 +1097,8 @@ int launch_layout(SgemmArgs a, bool vec, int64_t ws_floats, bool raw_partials, i
     // projection shapes: a shorter prologue and a finer interleave of staging and MFMAs -- still two blocks per CU, and
     // forcing three with __launch_bounds__(512, 6) is slower), 32 for A^T B (dW: -1.3 % with 16 in the compiler's VGPR
     // form, +-0 with AccVGPR accumulators) -- tools/gemm_exp.py, DESIGN.md section 4
+    // x W (dh) additionally keeps two K tiles in flight in registers (+2.8 %; logits +0.4 %, dW +-0: not worth their registers)
+    else if (big && vec && big_tile_threads() == 512 && !TA && !TB && bk16_on()) st = launch_cfg<128, 128, TA, TB, true, 512, 0, 16, 2>(a, stream);
     else if (big && vec && big_tile_threads() == 512 && !TA && bk16_on()) st = launch_cfg<128, 128, TA, TB, true, 512, 0, 16>(a, stream);
     else if (big && vec && big_tile_threads() == 512) st = launch_cfg<128, 128, TA, TB, true, 512>(a, stream);
     else if (big) st = vec ? launch_cfg<128, 128, TA, TB, true>(a, stream) : launch_cfg<128, 128, TA, TB, false>(a, stream);
