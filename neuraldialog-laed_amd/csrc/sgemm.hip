@@ -353,7 +353,12 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
             const float* a_s = a_base + CUR * BK * SA;
             const float* b_s = b_base + CUR * BK * SB;
 #if !defined(SGEMM_EXP) || !(SGEMM_EXP & 32)
-            if (advance) { ga += a_step; gb += b_step; }
+            {   // uniform (SGPR) select of the step, then one 64-bit add per pointer: a select between two POINTERS made the
+                // compiler split the following dwordx4 loads into dwordx2 halves with separate address arithmetic
+                const int64_t sa_ = advance ? a_step : 0, sb_ = advance ? b_step : 0;
+                ga += sa_;
+                gb += sb_;
+            }
 #endif
             // fragments are read TWO k pairs ahead (three register sets): the wait before a k pair's first MFMA then
             // covers reads issued a whole k pair (>= 256 cycles) earlier and leaves the newest reads in flight
