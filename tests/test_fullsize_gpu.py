@@ -206,3 +206,73 @@ def test_backward_at_headline_shape_matches_oracle_gradients(monkeypatch):
         d = float((after[n] - p).abs().max())
         assert d < 1e-4, (n, d)
     print("headline-shape gradient parity, worst rel err per tensor:", {n: "%.1e" % v for n, v in worst.items()})
+
+
+@pytest.mark.timeout(900)
+def test_divst_backward_at_headline_width_matches_oracle_gradients(monkeypatch):
+    """DI-VST (config 2's model) at the headline V / E / H / y / k / T with B = 128 sequences: one encoder, two decoders
+    that share the latent and the embedding and run -- forward and, replayed by autograd, backward -- on two HIP streams
+    (sent_models.py:363-442).  Against `oracle.divst_forward` + autograd: prev_nll / next_nll / reg_kl / b_pr at 1e-4,
+    every parameter gradient at 2e-4 (max-norm), parameters after one Adam step at 1e-4 absolute.
+
+    What this adds to the DI-VAE case above: the two-stream region at B > 64 (tiled GRU step kernels and 128x128 GEMMs
+    of two decoders in flight at once, each with its own projection workspace), the shared embedding's gradient summed
+    from three scatter-adds, the connector bias, and dh0 of two decoders meeting in the latent's backward."""
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from laed_amd.models.sent_models import DiVST
+    from oracle import laed_oracle as O
+    Bs = 128
+    monkeypatch.setenv("LAED_PROJ_CHUNK_ROWS", "2560")            # 4992 rows per decoder -> 2 chunks each
+    cfg = _config()
+    cfg.batch_size = Bs
+    torch.manual_seed(0)
+    model = DiVST(_Corpus(), cfg).cuda().train()
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    outs, prevs, nexts = (_batch(seed=s)[:Bs] for s in (4321, 4322, 4323))
+    rs = np.random.RandomState(12)
+    u = rs.uniform(size=(Bs * Y, K)).astype(np.float32)
+    keeps = [(rs.uniform(size=(Bs, T - 1, E)) >= 0.3).astype(np.uint8) for _ in range(2)]
+    ud = torch.from_numpy(u).cuda()
+    model.cat_connector.sample_uniform = lambda logits: ud
+    model.prev_decoder.injected_keep = torch.from_numpy(keeps[0]).cuda()
+    model.next_decoder.injected_keep = torch.from_numpy(keeps[1]).cuda()
+    opt = model.get_optimizer(cfg)
+    opt.zero_grad()
+    loss = model({"outputs": outs, "prevs": prevs, "nexts": nexts, "output_lens": [T] * Bs}, mode=TEACH_FORCE)
+    model.backward(0, loss)
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    opt.step()
+    torch.cuda.synchronize()
+    after = {n: p.detach().cpu() for n, p in model.named_parameters()}
+    got = {k: float(loss[k].detach()) for k in ("prev_nll", "next_nll", "reg_kl", "b_pr")}
+    del model, opt, loss
+    torch.cuda.empty_cache()
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for d in ("prev_decoder", "next_decoder"):
+        P[d + ".embedding.weight"] = P["embedding.weight"]
+    names = [k for k in P if not k.endswith("decoder.embedding.weight")]
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = O.divst_forward(P, cfg, outs, prevs, nexts, u, training=True,
+                          drop_masks=tuple(k.astype(np.float32) for k in keeps))
+    ref["total"].backward()
+    for k in got:
+        b = float(ref[k].detach())
+        assert abs(got[k] - b) <= 1e-7 + 1e-4 * abs(b), (k, got[k], b)
+    assert set(grads) == {k for k in names if P[k].grad is not None}
+    from helpers import rel_err
+    worst = {}
+    for n, g in grads.items():
+        worst[n] = rel_err(g, P[n].grad)
+        assert worst[n] < 2e-4, (n, worst[n])
+    for n in names:
+        if P[n].grad is None:
+            assert torch.equal(after[n], P[n].detach()), n
+            continue
+        p = P[n].detach().clone()
+        O.adam_step(p, P[n].grad, torch.zeros_like(p), torch.zeros_like(p), 1, lr=cfg.init_lr)
+        d = float((after[n] - p).abs().max())
+        assert d < 1e-4, (n, d)
+    print("DI-VST headline-width gradient parity, worst rel err per tensor:", {n: "%.1e" % v for n, v in worst.items()})
