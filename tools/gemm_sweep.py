@@ -21,7 +21,7 @@ SHAPES = [("logits NT  P", 1170, 10004, 512, "NT"), ("logits NT  VST", 2340, 100
 
 # the recurrence's per-timestep backward product dh = dgh W_hh at the S shape (H = 1024), per-GPU batches of 8/4/2 ranks
 RECUR = [("dh_rec NN B=512", 512, 1024, 3072, "NN"), ("dh_rec NN B=1024", 1024, 1024, 3072, "NN"),
-         ("dh_rec NN B=2048", 2048, 1024, 3072, "NN")]
+         ("dh_rec NN B=2048", 2048, 1024, 3072, "NN"), ("dh_rec NN B=4096", 4096, 1024, 3072, "NN")]
 
 
 def child(M, N, K, lay):
