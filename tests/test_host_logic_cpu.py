@@ -394,3 +394,27 @@ def test_projection_chunks_never_hold_a_whole_big_logits_tensor():
         assert rows * ops.proj_ldl(V) * 4 <= (8 << 30) + (1 << 20)
     assert ops.proj_chunk_rows(19968, 50000, 1024) == 9984
     assert ops.proj_chunk_rows(1170, 10002, 512) == 1170 and ops.proj_chunk_rows(2496, 50000, 1024) == 2496
+
+
+def test_persistent_recurrence_budget_streams_divide_processes_forbid(monkeypatch):
+    """The CU budget handed to laed_gru_{fwd,bwd}_cus: the whole device for one stream of one process, a share of it for
+    recurrences that run side by side on several streams of this process, and ONE CU -- i.e. never the persistent
+    kernels -- once another process shares the GPU (time-sliced spin grids: DESIGN.md section 5)."""
+    from types import SimpleNamespace
+    from laed_amd import ops
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: SimpleNamespace(multi_processor_count=256))
+    monkeypatch.setitem(ops._CU_SHARE, "streams", 1)
+    monkeypatch.setitem(ops._CU_SHARE, "processes", 1)
+    assert ops._cu_budget(0) == 0
+    with ops.concurrent_streams(2):
+        assert ops._cu_budget(0) == 128
+        with ops.concurrent_streams(4):
+            assert ops._cu_budget(0) == 64
+        assert ops._cu_budget(0) == 128
+    assert ops._cu_budget(0) == 0
+    ops.set_device_sharers(2)
+    assert ops._cu_budget(0) == 1
+    with ops.concurrent_streams(2):
+        assert ops._cu_budget(0) == 1
+    ops.set_device_sharers(1)
+    assert ops._cu_budget(0) == 0
