@@ -323,6 +323,12 @@ int laed_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* s
  * ------------------------------------------------------------------------------------------ */
 int laed_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
                    double lr, double beta1, double beta2, double eps, float grad_scale, void* stream);
+/* The same update for `ntensors` tensors in as few launches as their descriptors fit into kernel arguments (16 per
+ * launch); p, g, m, v, n are HOST arrays of device pointers / element counts.  All tensors share `step` (torch's Adam
+ * keeps one step count per parameter: the caller groups parameters by it).  Element-wise identical to laed_adam_step. */
+int laed_adam_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                         const int64_t* n, int step, double lr, double beta1, double beta2, double eps,
+                         float grad_scale, void* stream);
 
 /* The other two optimizers get_optimizer can build (model_bases.py:126-133): torch.optim.SGD(lr, momentum) and
  * torch.optim.RMSprop(lr, momentum) with torch's defaults (alpha 0.99, eps 1e-8, not centred); in place, state

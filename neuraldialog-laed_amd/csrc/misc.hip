@@ -13,22 +13,22 @@ extern "C" const char* laed_last_error(void) { return laed_err_buf(); }
 namespace {
 
 // torch.optim.Adam (no weight decay / amsgrad): 28 B of HBM traffic per parameter (read p,g,m,v; write p,m,v)
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n4, int64_t n, float step_size, float omb1, float b2,
-                                                   float omb2, float sqrt_bc2, float eps, float gs) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+struct AdamConsts { float step_size, omb1, b2, omb2, sqrt_bc2, eps, gs; };
+
+__device__ __forceinline__ void adam_range(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, int64_t n4, int64_t n, int64_t tid, int64_t stride,
+                                           const AdamConsts& c) {
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-#define ADAM1(P, G, M, V)                                   \
-    {                                                       \
-        const float gg = (G) * gs;                          \
-        (M) = (M) + omb1 * (gg - (M));      /* lerp_ */     \
-        (V) = (V) * b2 + (omb2 * gg) * gg;  /* addcmul_ */  \
-        const float den = sqrtf(V) / sqrt_bc2 + eps;        \
-        (P) = (P) - step_size * ((M) / den); /* addcdiv_ */ \
+#define ADAM1(P, G, M, V)                                         \
+    {                                                             \
+        const float gg = (G) * c.gs;                              \
+        (M) = (M) + c.omb1 * (gg - (M));        /* lerp_ */       \
+        (V) = (V) * c.b2 + (c.omb2 * gg) * gg;  /* addcmul_ */    \
+        const float den = sqrtf(V) / c.sqrt_bc2 + c.eps;          \
+        (P) = (P) - c.step_size * ((M) / den);  /* addcdiv_ */    \
     }
     for (int64_t i = tid; i < n4; i += stride) {
         float4 pp = p4[i], gg4 = g4[i], mm = m4[i], vv = v4[i];
@@ -44,6 +44,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 #undef ADAM1
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n4, int64_t n, AdamConsts c) {
+    adam_range(p, g, m, v, n4, n, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, c);
+}
+
+// Several tensors in one launch (the descriptors travel in the kernel arguments: no table in device memory).  Tensor t
+// owns blocks [blk0[t], blk0[t+1]) and is swept by them exactly as adam_kernel sweeps one tensor: same arithmetic per
+// element, so the results do not depend on the grouping.
+constexpr int ADAM_MAXT = 16;
+struct AdamMulti {
+    float* p[ADAM_MAXT];
+    const float* g[ADAM_MAXT];
+    float* m[ADAM_MAXT];
+    float* v[ADAM_MAXT];
+    int64_t n4[ADAM_MAXT], n[ADAM_MAXT];
+    int blk0[ADAM_MAXT + 1];
+    int nt;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti a, AdamConsts c) {
+    int t = 0;
+    while (t + 1 < a.nt && (int)blockIdx.x >= a.blk0[t + 1]) ++t;        // block-uniform
+    const int64_t nb = a.blk0[t + 1] - a.blk0[t];
+    adam_range(a.p[t], a.g[t], a.m[t], a.v[t], a.n4[t], a.n[t],
+               (int64_t)(blockIdx.x - a.blk0[t]) * blockDim.x + threadIdx.x, nb * blockDim.x, c);
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, float a, float b) {
@@ -91,18 +118,52 @@ inline int grid_for(int64_t n) {
 
 }   // namespace
 
+static AdamConsts adam_consts(int step, double lr, double beta1, double beta2, double eps, float grad_scale) {
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    AdamConsts c;
+    c.step_size = (float)(lr / bc1); c.omb1 = (float)(1.0 - beta1); c.b2 = (float)beta2; c.omb2 = (float)(1.0 - beta2);
+    c.sqrt_bc2 = (float)sqrt(bc2); c.eps = (float)eps; c.gs = grad_scale;
+    return c;
+}
+
 extern "C" int laed_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
                               double lr, double beta1, double beta2, double eps, float grad_scale, void* stream) {
     LAED_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad argument");
     if (n == 0) return 0;
     LAED_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
-    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
     const int64_t n4 = vec ? n / 4 : 0;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(vec ? n4 + 1 : n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n,
-                       (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
-                       grad_scale);
+                       adam_consts(step, lr, beta1, beta2, eps, grad_scale));
     LAED_LAUNCH_CHECK("adam_step");
+    return 0;
+}
+
+extern "C" int laed_adam_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                    const int64_t* n, int step, double lr, double beta1, double beta2, double eps,
+                                    float grad_scale, void* stream) {
+    LAED_CHECK_ARG(ntensors >= 0 && step >= 1, "adam_step_multi: bad argument");
+    LAED_CHECK_ARG(ntensors == 0 || (p && g && m && v && n), "adam_step_multi: null pointer table");
+    const AdamConsts c = adam_consts(step, lr, beta1, beta2, eps, grad_scale);
+    int t = 0;
+    while (t < ntensors) {
+        AdamMulti a;
+        a.nt = 0;
+        a.blk0[0] = 0;
+        for (; t < ntensors && a.nt < ADAM_MAXT; ++t) {
+            LAED_CHECK_ARG(n[t] >= 0, "adam_step_multi: negative size");
+            if (n[t] == 0) continue;
+            LAED_CHECK_ARG(p[t] && g[t] && m[t] && v[t], "adam_step_multi: null pointer");
+            const bool vec = aligned16(p[t]) && aligned16(g[t]) && aligned16(m[t]) && aligned16(v[t]);
+            const int k = a.nt++;
+            a.p[k] = p[t]; a.g[k] = g[t]; a.m[k] = m[t]; a.v[k] = v[t];
+            a.n[k] = n[t]; a.n4[k] = vec ? n[t] / 4 : 0;
+            a.blk0[k + 1] = a.blk0[k] + grid_for(vec ? a.n4[k] + 1 : n[t]);
+        }
+        if (a.nt == 0) break;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(a.blk0[a.nt]), dim3(256), 0, (hipStream_t)stream, a, c);
+        LAED_LAUNCH_CHECK("adam_step_multi");
+    }
     return 0;
 }
 

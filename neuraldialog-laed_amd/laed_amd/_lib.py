@@ -72,6 +72,7 @@ _SIGS = {
     "laed_tanh_fwd": ([_p, _p, _i64, _p], _i),
     "laed_tanh_bwd": ([_p, _p, _p, _i64, _p], _i),
     "laed_adam_step": ([_p, _p, _p, _p, _i64, _i, _d, _d, _d, _d, _f, _p], _i),
+    "laed_adam_step_multi": ([_i, _p, _p, _p, _p, _p, _i, _d, _d, _d, _d, _f, _p], _i),
     "laed_sgd_step": ([_p, _p, _p, _i64, _d, _d, _f, _p], _i),
     "laed_rmsprop_step": ([_p, _p, _p, _p, _i64, _d, _d, _d, _d, _f, _p], _i),
     "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),

@@ -77,6 +77,24 @@ def dropout_keep_mask(n, p, seed, offset, device):
     return keep
 
 
+def adam_step_multi(ps, gs, ms, vs, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """torch.optim.Adam's update for several parameter tensors that share the step count, in one launch per 16 tensors."""
+    import ctypes
+    n = len(ps)
+    if n == 0:
+        return
+    for t in list(ps) + list(gs) + list(ms) + list(vs):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.LaedError("adam_step_multi: fp32 contiguous tensors expected")
+    arr = lambda ts: (ctypes.c_void_p * n)(*[ptr(t).value for t in ts])        # ptr() refuses CPU tensors
+    sizes = (ctypes.c_int64 * n)(*[t.numel() for t in ps])
+    for a, b, c, d in zip(ps, gs, ms, vs):
+        if not (a.numel() == b.numel() == c.numel() == d.numel()):
+            raise _lib.LaedError("adam_step_multi: size mismatch")
+    check(lib.laed_adam_step_multi(n, arr(ps), arr(gs), arr(ms), arr(vs), sizes, int(step), lr, beta1, beta2, eps,
+                                   float(grad_scale), stream()), "laed_adam_step_multi")
+
+
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     check(lib.laed_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), int(step), lr, beta1, beta2, eps,
                              float(grad_scale), stream()), "laed_adam_step")

@@ -24,6 +24,7 @@ class FusedAdam(object):
     def step(self):
         if self.reducer is not None:
             self.reducer.wait()
+        by_step = {}                    # torch's Adam counts steps per parameter: one launch group per count
         for p in self.params:
             if p.grad is None:          # e.g. log_py without train_prior: torch's Adam skips grad-less params
                 continue
@@ -32,7 +33,11 @@ class FusedAdam(object):
                 st = self.state[p] = {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)}
             st["step"] += 1
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            ops.adam_step(p.data, g, st["m"], st["v"], st["step"], self.lr, self.betas[0], self.betas[1], self.eps)
+            grp = by_step.setdefault(st["step"], ([], [], [], []))
+            for lst, t in zip(grp, (p.data, g, st["m"], st["v"])):
+                lst.append(t)
+        for step, (ps, gs, ms, vs) in by_step.items():
+            ops.adam_step_multi(ps, gs, ms, vs, step, self.lr, self.betas[0], self.betas[1], self.eps)
 
     def state_dict(self):
         return {"lr": self.lr, "betas": self.betas, "eps": self.eps,

@@ -594,6 +594,32 @@ def test_adam(ops, O):
     assert rel_err(pg.cpu(), p) < 1e-6 and rel_err(mg.cpu(), m) < 1e-6 and rel_err(vg.cpu(), v) < 1e-6
 
 
+def test_adam_multi_tensor_equals_single_tensor_launches(ops):
+    """laed_adam_step_multi: 37 tensors (three launches of <= 16 descriptors), sizes from 1 to 300 001 elements, odd
+    sizes, an empty tensor and 4-byte-aligned views (scalar path) -- bit-identical to one laed_adam_step per tensor."""
+    sizes = [1, 3, 4, 5, 255, 256, 257, 1024, 4099, 300001, 0, 77] + [1000 + 13 * i for i in range(25)]
+    base = [dev(rnd(n + 1, seed=10 + i)) for i, n in enumerate(sizes)]
+    mk = lambda i, n, seed, scale=1.0: (dev(rnd(n + 1, seed=seed + i, scale=scale))[1:] if i % 5 == 2
+                                        else dev(rnd(n, seed=seed + i, scale=scale)))       # every fifth one unaligned
+    P = [mk(i, n, 100) for i, n in enumerate(sizes)]
+    G = [mk(i, n, 200, 0.01) for i, n in enumerate(sizes)]
+    M = [torch.zeros_like(t) for t in P]
+    V_ = [torch.zeros_like(t) for t in P]
+    P2, M2, V2 = [t.clone() for t in P], [t.clone() for t in M], [t.clone() for t in V_]
+    for step in (1, 2, 3):
+        ops.adam_step_multi([t for t in P], G, M, V_, step, 1e-3)
+        for p, g, m, v in zip(P2, G, M2, V2):
+            if p.numel():
+                ops.adam_step(p, g, m, v, step, 1e-3)
+    for a, b in zip(P + M + V_, P2 + M2 + V2):
+        assert torch.equal(a, b)
+    from laed_amd._lib import LaedError
+    with pytest.raises(LaedError):
+        ops.adam_step_multi([P[3]], [G[4]], [M[3]], [V_[3]], 1, 1e-3)        # size mismatch
+    with pytest.raises(LaedError):
+        ops.adam_step_multi([P[3].cpu()], [G[3]], [M[3]], [V_[3]], 1, 1e-3)  # no CPU path
+
+
 def test_argmax_logsoftmax_greedy(ops, O):
     N, V = 37, 1003
     logits = rnd(N, V, seed=1, scale=4.0)
