@@ -255,7 +255,9 @@ int laed_argmax_rows(const float* logits, int64_t N, int V, int ldl, int64_t* id
 
 /* Greedy free-running decode, max_len steps from h0 (DecoderRNN GEN/greedy, decoders.py:180-192,258-268):
  * ids_out[(max_len+1)][B]: row 0 = go_id, row t+1 = symbols chosen at step t; hbuf[(max_len+1)][B][H] as in
- * laed_gru_fwd; xbuf[B][E], gates[B][3H], logits[B][laed_proj_nll_ldl(V)] are caller-provided scratch. */
+ * laed_gru_fwd; xbuf[B][E], gates[B][3H], logits[B][laed_proj_nll_ldl(V)] are caller-provided scratch.  In the exact-fp32
+ * mode and from 512 output tiles of 128 x 128 upwards the symbols come out of the projection GEMM's arg-max epilogue and
+ * the scratch only ever holds [ceil(V/128)][B][2] per-tile partials: the [B][V] logits are not written. */
 int laed_gru_decode_greedy(const float* emb, const float* w_ih, const float* w_hh, const float* b_ih,
                            const float* b_hh, const float* proj_w, const float* proj_b, const float* h0,
                            int B, int E, int H, int V, int max_len, int64_t go_id,

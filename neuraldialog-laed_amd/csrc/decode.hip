@@ -85,11 +85,22 @@ int decode_loop(const float* emb, const float* w_ih, const float* w_hh, const fl
     }
     hipLaunchKernelGGL(fill_ids_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ids_out, B, go_id);
     LAED_LAUNCH_CHECK("fill_ids");
+    // exact-fp32 mode with at least a round of 128x128 tiles: the arg-max comes out of the GEMM (2 * ceil(V/128) <= ldl,
+    // so the partials fit the scratch); smaller problems and the split-bf16 mode keep the two-kernel path
+    const bool fused_argmax = laed_get_gemm_mode() == 0 && (int64_t)((B + 127) / 128) * ((V + 127) / 128) >= 512 &&
+                              2 * ((V + 127) / 128) <= ldl;
     for (int t = 0; t < max_len; ++t) {
         const int64_t* ids = ids_out + (int64_t)t * B;
         LAED_TRY(laed_embed_gather(ids, B, emb, V, E, nullptr, 0.f, xbuf, stream_));
         LAED_TRY(laed_sgemm_impl(false, true, B, 3 * H, E, xbuf, E, w_ih, E, gates, 3 * H, b_ih, false, nullptr, false, stream));
         LAED_TRY(laed_gru_step_impl(hbuf + (int64_t)t * BH, w_hh, b_hh, gates, hbuf + (int64_t)(t + 1) * BH, nullptr, B, H, stream));
+        if (!sample && fused_argmax) {
+            // greedy: per-tile (max, column) from the projection's epilogue, reduced over the tiles -- the [B][V] logits
+            // are never written; the scratch holds the [tiles][B][2] partials instead
+            LAED_TRY(laed_sgemm_argmax_impl(B, V, H, hbuf + (int64_t)(t + 1) * BH, H, proj_w, H, proj_b, logits,
+                                            ids_out + (int64_t)(t + 1) * B, stream));
+            continue;
+        }
         LAED_TRY(laed_sgemm_impl(false, true, B, V, H, hbuf + (int64_t)(t + 1) * BH, H, proj_w, H, logits, ldl, proj_b, false,
                                  nullptr, false, stream));
         if (!sample) {

@@ -88,6 +88,8 @@ int laed_sgemm_splitk_impl(bool transA, bool transB, int M, int N, int K,
 
 int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                   const float* bias, const int64_t* labels, float* part, float* lab_logit, hipStream_t stream);
+int laed_sgemm_argmax_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           const float* bias, float* part, int64_t* ids, hipStream_t stream);
 
 extern "C" int laed_get_gemm_mode(void);
 int laed_xgemm_nt_launch(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,

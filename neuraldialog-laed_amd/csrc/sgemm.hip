@@ -512,6 +512,52 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         return;
     }
 
+    if (EPI == 2) {
+        // ---- arg-max epilogue (greedy decode): per row of the block tile the largest logit of its BN columns and that
+        // column's index -- lowest index on ties, as laed_argmax_rows -- and nothing else leaves the block.  Same
+        // lane / wave order as the softmax epilogue above; the index travels as the bits of a float.
+        float* red = smem;                      // [WGN][BM][2]
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * (BN / WGN) + j * 32 + lrow;
+                    if (col < p.N) {
+                        const float v = acc[i][j][e] + (p.bias != nullptr ? p.bias[col] : 0.f);
+                        if (v > bv) { bv = v; bi = col; }
+                    }
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lrow == 0) { red[(wn * BM + rl) * 2] = bv; red[(wn * BM + rl) * 2 + 1] = __int_as_float(bi); }
+            }
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float bv = red[tid * 2];
+            int bi = __float_as_int(red[tid * 2 + 1]);
+#pragma unroll
+            for (int w = 1; w < WGN; ++w) {
+                const float ov = red[(w * BM + tid) * 2];
+                const int oi = __float_as_int(red[(w * BM + tid) * 2 + 1]);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            float* dst = p.part + ((int64_t)tile_n * p.M + (m0 + tid)) * 2;
+            dst[0] = bv;
+            dst[1] = __int_as_float(bi);
+        }
+        return;
+    }
+
     // ---- epilogue
     store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
 
@@ -930,7 +976,7 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
     constexpr size_t lds_tiles = (size_t)2 * BKT * (SA + SB) * sizeof(float);
     // the epilogues reuse the tile memory: online-softmax partials [NT/128][BM][2], column sums [NT/(BM/4)][BM/4][4]
-    constexpr size_t lds_epi = (size_t)(EPI == 1 ? (NT / 128) * BM * 2 : (TA ? NT * 4 : 0)) * sizeof(float);
+    constexpr size_t lds_epi = (size_t)(EPI != 0 ? (NT / 128) * BM * 2 : (TA ? NT * 4 : 0)) * sizeof(float);
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     auto kern = sgemm_kernel<BM, BN, TA, TB, VEC, NT, EPI, BKT, PF>;
     static uint64_t attr_set = 0;   // per device
@@ -1212,6 +1258,51 @@ int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t l
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     return vec ? launch_cfg<128, 128, false, true, true, 512, 1>(a, stream)
                : launch_cfg<128, 128, false, true, false, 512, 1>(a, stream);
+}
+
+// Greedy symbol selection without the logits: for x[M][K] W[N][K]^T + bias, per 128-column tile the largest value of
+// every row and its column (lowest column on ties); part: [ceil(N/128)][M][2] floats (value, column index as bits),
+// reduced over the tiles by argmax_tiles_kernel.  The [M][N] product is never written.
+namespace {
+__global__ __launch_bounds__(256) void argmax_tiles_kernel(const float* __restrict__ part, int M, int tiles, int64_t* __restrict__ ids) {
+    // one wave per row: the lanes stride over the column tiles, then meet in a shuffle tree (largest value, lowest column)
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = lane; t < tiles; t += 64) {    // ascending columns per lane: strict > keeps the lane's first maximum
+        const float2 r = *reinterpret_cast<const float2*>(part + ((int64_t)t * M + m) * 2);
+        if (r.x > bv) { bv = r.x; bi = __float_as_int(r.y); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) ids[m] = bi == 0x7fffffff ? 0 : bi;        // a row of NaN / -inf only: 0, as laed_argmax_rows
+}
+}   // namespace
+
+int laed_sgemm_argmax_impl(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           const float* bias, float* part, int64_t* ids, hipStream_t stream) {
+    LAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && part && ids, "sgemm_argmax: bad argument");
+    LAED_CHECK_ARG(lda >= K && ldb >= K, "sgemm_argmax: leading dimension too small");
+    SgemmArgs a;
+    a.A = A; a.B = B; a.C = nullptr; a.bias = bias; a.colsum = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = 0;
+    a.M = M; a.N = N; a.K = K;
+    a.accumulate = 0; a.colsum_acc = 0;
+    a.tiles_m = a.tiles_n = 0; a.group_m = 8;
+    a.splitk = 1; a.kper = ((K + BK - 1) / BK) * BK; a.ws = nullptr; a.ws_colsum = nullptr;
+    a.labels = nullptr; a.part = part; a.lab_logit = nullptr;
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    LAED_TRY((vec ? launch_cfg<128, 128, false, true, true, 512, 2, 16>(a, stream)
+                  : launch_cfg<128, 128, false, true, false, 512, 2>(a, stream)));
+    hipLaunchKernelGGL(argmax_tiles_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, part, M, (N + 127) / 128, ids);
+    LAED_LAUNCH_CHECK("argmax_tiles");
+    return 0;
 }
 
 // NT product with row sums of A (bf16x3 mode only: the split-bf16 kernel sums its own A-operand registers).

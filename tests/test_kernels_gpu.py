@@ -620,6 +620,30 @@ def test_adam_multi_tensor_equals_single_tensor_launches(ops):
         ops.adam_step_multi([P[3].cpu()], [G[3]], [M[3]], [V_[3]], 1, 1e-3)  # no CPU path
 
 
+def test_greedy_decode_argmax_from_the_gemm_epilogue(ops):
+    """Greedy decode at >= 512 output tiles takes its symbols from the projection's arg-max epilogue (no [B][V] logits):
+    every step must equal laed_proj_argmax (logits GEMM + laed_argmax_rows) on that step's hidden state, including
+    exact ties (two identical vocabulary rows: the lower index wins) and the ragged last column tile (V % 128 != 0)."""
+    B, E, H, V, L = 300, 24, 96, 33001, 6                     # 3 x 258 = 774 tiles of 128 x 128
+    emb, w_ih, w_hh = dev(rnd(V, E, seed=1)), dev(rnd(3 * H, E, seed=2, scale=0.3)), dev(rnd(3 * H, H, seed=3, scale=0.3))
+    b_ih, b_hh = dev(rnd(3 * H, seed=4, scale=0.1)), dev(rnd(3 * H, seed=5, scale=0.1))
+    W, b = rnd(V, H, seed=6, scale=0.5), rnd(V, seed=7, scale=0.1)
+    W[32999] = W[17]                                          # an exact tie ...
+    b[32999] = b[17] = 0.0
+    W[17] *= 3.0                                              # ... that wins many rows
+    W[32999] *= 3.0
+    Wd, bd = dev(W), dev(b)
+    h0 = dev(rnd(B, H, seed=8))
+    ids, hbuf = ops.decode_greedy(emb, w_ih, w_hh, b_ih, b_hh, Wd, bd, h0, L, 2)
+    n_tie = 0
+    for t in range(L):
+        ref = ops.proj_argmax(hbuf[t + 1].contiguous(), Wd, bd)
+        assert torch.equal(ids[t], ref), t
+        n_tie += int((ref == 17).sum())
+        assert int((ref == 32999).sum()) == 0
+    assert n_tie > 0
+
+
 def test_argmax_logsoftmax_greedy(ops, O):
     N, V = 37, 1003
     logits = rnd(N, V, seed=1, scale=4.0)
