@@ -466,13 +466,25 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         // lane>>5, so xor-shuffles up to 16 reduce them; the WGN waves that cover the tile's columns meet in LDS and are
         // combined in wave order (fixed order: reproducible).
         float* red = smem;                      // [WGN][BM][2]; every wave is past the main loop's last barrier
+        // the labels of this lane's 32 rows, fetched in one batch: read one by one inside the loop below they were 32
+        // dependent round trips per wave (each behind the previous row's lab_logit store, which may alias them) -- the
+        // epilogue then took about as long as the tile's K loop (validation forward 387 ms at the scaled shape)
+        int labs[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                const int64_t l64 = (row < p.M) ? p.labels[row] : -1;
+                labs[i][e] = (l64 >= 0 && l64 < p.N) ? (int)l64 : -1;
+            }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rl = wm * (BM / WGM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 const int row = m0 + rl;
-                const int64_t lab = (row < p.M) ? p.labels[row] : -1;
+                const int lab = labs[i][e];
                 float v[TN];
                 float m = -INFINITY;
 #pragma unroll
@@ -481,7 +493,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
                     v[j] = -INFINITY;
                     if (col < p.N) {
                         v[j] = acc[i][j][e] + (p.bias != nullptr ? p.bias[col] : 0.f);
-                        if ((int64_t)col == lab) p.lab_logit[row] = v[j];
+                        if (col == lab) p.lab_logit[row] = v[j];
                     }
                     m = fmaxf(m, v[j]);
                 }
@@ -1256,7 +1268,7 @@ int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t l
     a.splitk = 1; a.kper = ((K + BK - 1) / BK) * BK; a.ws = nullptr; a.ws_colsum = nullptr;
     a.labels = labels; a.part = part; a.lab_logit = lab_logit;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
-    return vec ? launch_cfg<128, 128, false, true, true, 512, 1>(a, stream)
+    return vec ? launch_cfg<128, 128, false, true, true, 512, 1, 16>(a, stream)
                : launch_cfg<128, 128, false, true, false, 512, 1>(a, stream);
 }
 

@@ -49,7 +49,8 @@ class NLLEntropy(_Loss):
             scale_tm = self._row_scale(labels, B, T).t().contiguous().view(-1)
             labels_tm = labels.t().contiguous().view(-1)
             loss, tok = ops.ProjNLLFunction.apply(net_output.h_tm.reshape(B * T, -1), net_output.project.weight,
-                                                  net_output.project.bias, labels_tm, scale_tm, self.padding_idx)
+                                                  net_output.project.bias, labels_tm, scale_tm, self.padding_idx,
+                                                  torch.is_grad_enabled())
             net_output.tok_nll = tok.view(T, B).t()
             return loss
         # a materialised [B,T,V] log-prob tensor: label gather + weighted sum on the HIP kernels (batch-first rows)

@@ -41,9 +41,9 @@ class GRU(nn.Module):
     def forward_tm(self, x_tm, h0=None, reverse=False):
         """Time-major entry: x_tm [T,B,E], h0 [B,H] -> (out_tm [T,B,H], hT [B,H])."""
         if reverse:
-            out, hT = ops.GRUFunction.apply(x_tm.flip(0), *self._params('_reverse'), h0)
+            out, hT = ops.GRUFunction.apply(x_tm.flip(0), *self._params('_reverse'), h0, torch.is_grad_enabled())
             return out.flip(0), hT
-        return ops.GRUFunction.apply(x_tm, *self._params(''), h0)
+        return ops.GRUFunction.apply(x_tm, *self._params(''), h0, torch.is_grad_enabled())
 
     def forward(self, x, hx=None):
         """nn.GRU(batch_first=True) contract: x [B,T,E], hx [dirs,B,H] -> (out [B,T,H*dirs], h_n [dirs,B,H]).

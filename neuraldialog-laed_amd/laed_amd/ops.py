@@ -401,21 +401,25 @@ class GRUFunction(torch.autograd.Function):
     """x[T,B,E] (time-major) -> out[T,B,H], hT[B,H]."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, taped=True):
         x = _f32c(x)
         T, B, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
         hbuf = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
         gates = torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32)
-        hn = torch.empty((T, B, H), device=dev, dtype=torch.float32)
+        # `taped` = the caller's torch.is_grad_enabled() (see ProjNLLFunction.forward): without a tape the step kernels
+        # skip the reserve space (r, z, n and W_hn h + b_hn: four of the nine floats they move per output)
+        keep = bool(taped) and any(ctx.needs_input_grad[:6])
+        hn = torch.empty((T, B, H), device=dev, dtype=torch.float32) if keep else None
         h0c = _f32c(h0) if h0 is not None else None
         ws_n = int(lib.laed_gru_fwd_workspace(T, B, E, H))         # packed operands of the small-batch step kernels
         ws = workspace("gru_ws", ws_n, dev) if ws_n > 0 else None
         ctx.cu_budget = _cu_budget(dev)
         check(lib.laed_gru_fwd_cus(ptr(x), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(h0c), T, B, E, H,
                                    ptr(hbuf), ptr(gates), ptr(hn), ptr(ws), ws_n, ctx.cu_budget, stream()), "laed_gru_fwd")
-        ctx.save_for_backward(x, w_ih, w_hh, hbuf, gates, hn)
+        if keep:
+            ctx.save_for_backward(x, w_ih, w_hh, hbuf, gates, hn)
         ctx.has_h0 = h0 is not None
         out = hbuf[1:]
         hT = hbuf[T]
@@ -443,7 +447,7 @@ class GRUFunction(torch.autograd.Function):
         check(lib.laed_gru_bwd_cus(ptr(x), ptr(w_ih), ptr(w_hh), ptr(hbuf), ptr(gates), ptr(hn), ptr(dout), ptr(dhT),
                                    T, B, E, H, ptr(dgh), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), 0,
                                    ptr(ws), ws_n, ctx.cu_budget, stream()), "laed_gru_bwd")
-        return dx, dw_ih, dw_hh, db_ih, db_hh, (dh0 if ctx.has_h0 else None)
+        return dx, dw_ih, dw_hh, db_ih, db_hh, (dh0 if ctx.has_h0 else None), None
 
 
 class GumbelLatentFunction(torch.autograd.Function):
@@ -753,9 +757,13 @@ class ProjNLLFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, h, W, b, labels, row_scale, pad_id):
+    def forward(ctx, h, W, b, labels, row_scale, pad_id, taped=True):
         h = _f32c(h)
-        with_grad = any(ctx.needs_input_grad[:3])
+        # `taped` = the caller's torch.is_grad_enabled(): inside forward() grad mode is always off, and needs_input_grad
+        # only mirrors requires_grad of the inputs -- under no_grad (validation, engine.validate) W still "needs" a
+        # gradient and the whole backward half (softmax-CE rows, dh and dW products: 2/3 of the FLOPs) would run for
+        # nothing (measured: 384 ms per validation batch at the scaled shape instead of ~150)
+        with_grad = bool(taped) and any(ctx.needs_input_grad[:3])
         tok, lse, dh, dW, db = proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad)
         loss = torch.empty(1, device=h.device, dtype=torch.float32)
         check(lib.laed_dot(ptr(tok), ptr(row_scale), tok.numel(), ptr(loss), stream()), "laed_dot")
@@ -772,7 +780,7 @@ class ProjNLLFunction(torch.autograd.Function):
         g = _f32c(dloss).reshape(1)
         for t in (dh, dW, db):
             check(lib.laed_scale_by_dev(ptr(t), ptr(t), ptr(g), t.numel(), stream()), "laed_scale_by_dev")
-        return dh, dW, db, None, None, None
+        return dh, dW, db, None, None, None, None
 
 
 class SoftmaxEmbedFunction(torch.autograd.Function):

@@ -296,3 +296,29 @@ def test_latent_analysis_entry_points_vs_reference():
         ctx, ids = model.exp_enumerate()
         assert np.array_equal(np.array(ids), G["exp_enumerate/all_y_ids"])
         assert np.array_equal(stack(ctx), G["exp_enumerate/sequence"])
+
+
+def test_no_grad_forward_runs_no_backward_kernels(monkeypatch):
+    """engine.validate runs the model under torch.no_grad() (main.py:165-181).  The fused projection + NLL must then take
+    its forward-only path (no softmax-CE gradient rows, no dh / dW products) and the recurrences must not keep a reserve
+    space -- autograd's needs_input_grad alone cannot tell (it mirrors requires_grad of the weights) -- with the same loss."""
+    from laed_amd import ops
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    G = load_golden("divae_tiny")
+    model, cfg = build(G, "divae")
+    model.eval()
+    inject_u(model, G["in/u_steps"][0])
+    feed = {"outputs": G["in/outputs"], "output_lens": [G["in/outputs"].shape[1]] * G["in/outputs"].shape[0]}
+    seen = []
+    raw = ops.proj_nll_raw
+    monkeypatch.setattr(ops, "proj_nll_raw", lambda *a, **k: (seen.append(bool(a[6])), raw(*a, **k))[1])
+    gru_fwd = ops.lib.laed_gru_fwd_cus
+    hn_args = []
+    monkeypatch.setattr(ops.lib, "laed_gru_fwd_cus", lambda *a: (hn_args.append(a[12]), gru_fwd(*a))[1])
+    with torch.no_grad():
+        quiet = model(feed, mode=TEACH_FORCE)
+    assert seen == [False] and all(h is None for h in hn_args) and len(hn_args) == 2
+    seen.clear(); hn_args.clear()
+    taped = model(feed, mode=TEACH_FORCE)
+    assert seen == [True] and all(h is not None for h in hn_args)
+    assert close(quiet.nll, float(taped.nll.detach()), rtol=1e-6)
