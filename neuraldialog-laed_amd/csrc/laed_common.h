@@ -118,6 +118,22 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Lane exchange for a butterfly reduction over the 32 lanes that share lane>>5, stage `o` = 1, 2, 4, 8, 16: the partner of
+// __shfl_xor(v, o), but by DPP (a VALU modifier: no LDS crossbar round trip, no lgkmcnt wait) for the four stages inside a
+// row of 16 lanes.  Stages 4 and 8 use the mirror permutations, which pair the same GROUPS as xor 4 / xor 8; since every
+// lane of a group already holds the group's value after the earlier stages, the reduction tree -- and for sums the
+// association order -- is exactly the xor butterfly's.  Only the 16-stage crosses rows and stays a ds_bpermute.
+template <int O>
+__device__ __forceinline__ int laed_bfly32_i(int v) {
+    if (O == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    if (O == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    if (O == 4) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    if (O == 8) return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+    return __shfl_xor(v, 16, 64);
+}
+template <int O>
+__device__ __forceinline__ float laed_bfly32(float v) { return __int_as_float(laed_bfly32_i<O>(__float_as_int(v))); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

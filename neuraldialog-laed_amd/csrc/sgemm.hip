@@ -497,13 +497,13 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
                     }
                     m = fmaxf(m, v[j]);
                 }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                m = fmaxf(m, laed_bfly32<1>(m)); m = fmaxf(m, laed_bfly32<2>(m)); m = fmaxf(m, laed_bfly32<4>(m));
+                m = fmaxf(m, laed_bfly32<8>(m)); m = fmaxf(m, laed_bfly32<16>(m));
                 float sum = 0.f;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) sum += (v[j] == -INFINITY) ? 0.f : expf(v[j] - m);
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                sum += laed_bfly32<1>(sum); sum += laed_bfly32<2>(sum); sum += laed_bfly32<4>(sum);
+                sum += laed_bfly32<8>(sum); sum += laed_bfly32<16>(sum);
                 if (lrow == 0) { red[(wn * BM + rl) * 2] = m; red[(wn * BM + rl) * 2 + 1] = sum; }
             }
         }
@@ -544,12 +544,14 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
                         if (v > bv) { bv = v; bi = col; }
                     }
                 }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+#define LAED_ARGMAX_STAGE(O)                                                        \
+                {                                                                   \
+                    const float ov = laed_bfly32<O>(bv);                            \
+                    const int oi = laed_bfly32_i<O>(bi);                            \
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }     \
                 }
+                LAED_ARGMAX_STAGE(1) LAED_ARGMAX_STAGE(2) LAED_ARGMAX_STAGE(4) LAED_ARGMAX_STAGE(8) LAED_ARGMAX_STAGE(16)
+#undef LAED_ARGMAX_STAGE
                 if (lrow == 0) { red[(wn * BM + rl) * 2] = bv; red[(wn * BM + rl) * 2 + 1] = __int_as_float(bi); }
             }
         }
