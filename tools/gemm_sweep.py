@@ -24,6 +24,11 @@ RECUR = [("dh_rec NN B=512", 512, 1024, 3072, "NN"), ("dh_rec NN B=1024", 1024, 
          ("dh_rec NN B=2048", 2048, 1024, 3072, "NN"), ("dh_rec NN B=4096", 4096, 1024, 3072, "NN")]
 
 
+# the attribute head of AE-ED / ST-ED (softmax(dec_outs) @ x_embedding.weight and its backward; B = 30, V = 10004, E = 200)
+ATTR = [("p Wemb NN", 1170, 200, 10004, "NN"), ("dWemb TN", 10004, 200, 1170, "TN"), ("dp NT", 1170, 10004, 200, "NT"),
+        ("logits NT", 1170, 10004, 256, "NT"), ("dh NN", 1170, 256, 10004, "NN"), ("dW TN", 10004, 256, 1170, "TN")]
+
+
 def child(M, N, K, lay):
     import torch
     from laed_amd import ops
@@ -48,7 +53,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
         sys.exit(0)
-    for name, M, N, K, lay in (RECUR if "--recur" in sys.argv else SHAPES):
+    for name, M, N, K, lay in (RECUR if "--recur" in sys.argv else ATTR if "--attr" in sys.argv else SHAPES):
         res = {}
         forces = [] if "--heuristic-only" in sys.argv else ["%d,%d" % (t, s) for t in (64, 128) for s in (1, 2, 3, 4, 6, 8, 12, 16)]
         for force in [None] + forces:
