@@ -9,7 +9,11 @@ import math
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import ops
+
+_BIDIR_STREAMS = os.environ.get("LAED_BIDIR_STREAMS", "1") != "0"     # the two directions of a bidirectional GRU side by side
 
 PAD = '<pad>'      # laed/dataset/corpora.py:14-17
 UNK = '<unk>'
@@ -34,6 +38,10 @@ class GRU(nn.Module):
         stdv = 1.0 / math.sqrt(hidden_size)
         for w in self.parameters():
             nn.init.uniform_(w, -stdv, stdv)
+        self._side_stream = None
+        if bidirectional and _BIDIR_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # the reverse direction's parameters are produced on the side stream and accumulated on the default one: intended
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     def _params(self, sfx):
         return [getattr(self, n + sfx) for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
@@ -49,10 +57,29 @@ class GRU(nn.Module):
         """nn.GRU(batch_first=True) contract: x [B,T,E], hx [dirs,B,H] -> (out [B,T,H*dirs], h_n [dirs,B,H]).
         `out` is a batch-first view of time-major memory; x given as such a view is consumed without a copy."""
         x_tm = x.transpose(0, 1)                  # [T,B,E]; contiguous already when x came from laed_amd.Embedding
-        out_f, h_f = self.forward_tm(x_tm, None if hx is None else hx[0])
         if not self.bidirectional:
+            out_f, h_f = self.forward_tm(x_tm, None if hx is None else hx[0])
             return out_f.transpose(0, 1), h_f.unsqueeze(0)
-        out_b, h_b = self.forward_tm(x_tm, None if hx is None else hx[1], reverse=True)
+        if x.is_cuda and _BIDIR_STREAMS:
+            # the two directions are independent recurrences of launch-bound step kernels (the utterance encoder of
+            # AE-ED / ST-ED: 300 sequences x 40 steps each way): the reverse one runs on a side HIP stream beside the
+            # forward one; autograd replays every node on its forward stream, so backward overlaps the same way
+            cur = torch.cuda.current_stream(x.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=x.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with ops.concurrent_streams(2):          # a persistent recurrence may only count on half the CUs
+                with torch.cuda.stream(side):
+                    out_b, h_b = self.forward_tm(x_tm, None if hx is None else hx[1], reverse=True)
+                out_f, h_f = self.forward_tm(x_tm, None if hx is None else hx[0])
+            x_tm.record_stream(side)
+            for t in (out_b, h_b):
+                t.record_stream(cur)
+            cur.wait_stream(side)
+        else:
+            out_f, h_f = self.forward_tm(x_tm, None if hx is None else hx[0])
+            out_b, h_b = self.forward_tm(x_tm, None if hx is None else hx[1], reverse=True)
         return torch.cat([out_f, out_b], dim=2).transpose(0, 1), torch.stack([h_f, h_b], dim=0)
 
 
