@@ -11,6 +11,7 @@ parallelism for these two models.  valid_loss sums out of place (the reference's
 dialog_models.py:280-284).
 """
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -103,6 +104,34 @@ class LAED(BaseModel):
         return Pack(qy_logits=qy_logits, sample_y=sample_y, y_ids=y_ids, log_qy=log_qy)
 
     # ---- context encoder + prior network p(y|c)  (dialog_models.py:331-338)
+    def _two_branches(self, main_fn, side_fn, *side_inputs):
+        """(main_fn(), side_fn()) for two branches that share no intermediate result: the recognition / auto-encoder
+        branch and the context branch of AE-ED / ST-ED (dialog_models.py:383-389 computes them one after the other).
+        On the GPU the side branch runs on a second HIP stream beside the main one -- both are chains of launch-bound
+        small-batch kernels -- and autograd replays each on its forward stream (LAED_BRANCH_STREAMS=0: one stream)."""
+        dev = side_inputs[0].device if side_inputs else None
+        if dev is None or dev.type != "cuda" or os.environ.get("LAED_BRANCH_STREAMS", "1") == "0":
+            a = main_fn()
+            return a, side_fn()
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_branch_stream", None) is None:
+            self._branch_stream = torch.cuda.Stream(device=dev)
+            if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        side = self._branch_stream
+        side.wait_stream(cur)
+        with ops.concurrent_streams(2):
+            a = main_fn()                          # same host order as the one-stream path: same dropout / Gumbel draws
+            with torch.cuda.stream(side):
+                for t in side_inputs:
+                    t.record_stream(side)
+                b = side_fn()
+        for t in (b if isinstance(b, (tuple, list)) else (b,)):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+        cur.wait_stream(side)
+        return a, b
+
     def _context_prior(self, ctx_utts, ctx_lens, with_fc1=True):
         c_inputs = self.utt_encoder(ctx_utts)
         c_outs, c_last = self.ctx_encoder(c_inputs, ctx_lens)
@@ -262,8 +291,9 @@ class AeED(LAED):
         ctx_utts = self.np2var(data_feed['contexts'], LONG)
         out_utts = self.np2var(data_feed['outputs'], LONG)
 
-        vae_resp = self.pxz_forward(batch_size, self.qzx_forward(out_utts[:, 1:]), out_utts, mode, gen_type)
-        c_outs, c_last, py_logits, log_py = self._context_prior(ctx_utts, ctx_lens)
+        vae_resp, (c_outs, c_last, py_logits, log_py) = self._two_branches(
+            lambda: self.pxz_forward(batch_size, self.qzx_forward(out_utts[:, 1:]), out_utts, mode, gen_type),
+            lambda: self._context_prior(ctx_utts, ctx_lens), ctx_utts)
 
         qy_id = vae_resp.y_ids.detach().view(-1, self.config.y_size)
         if mode != GEN:
@@ -340,8 +370,9 @@ class StED(LAED):
         prev_utts = self.np2var(data_feed['prevs'], LONG)
         next_utts = self.np2var(data_feed['nexts'], LONG)
 
-        vst_resp = self.pxz_forward(batch_size, self.qzx_forward(out_utts[:, 1:]), prev_utts, next_utts, mode, gen_type)
-        c_outs, c_last, py_logits, log_py = self._context_prior(ctx_utts, ctx_lens)
+        vst_resp, (c_outs, c_last, py_logits, log_py) = self._two_branches(
+            lambda: self.pxz_forward(batch_size, self.qzx_forward(out_utts[:, 1:]), prev_utts, next_utts, mode, gen_type),
+            lambda: self._context_prior(ctx_utts, ctx_lens), ctx_utts)
 
         qy_id = vst_resp.y_ids.detach().view(-1, self.config.y_size)
         if mode != GEN:

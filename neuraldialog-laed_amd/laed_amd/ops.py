@@ -366,7 +366,7 @@ class concurrent_streams(object):
 
     def __enter__(self):
         self.prev = _CU_SHARE["streams"]
-        _CU_SHARE["streams"] = self.n
+        _CU_SHARE["streams"] = self.prev * self.n          # nested regions multiply (a bidirectional GRU inside a branch)
         return self
 
     def __exit__(self, *exc):

@@ -408,8 +408,8 @@ def test_persistent_recurrence_budget_streams_divide_processes_forbid(monkeypatc
     assert ops._cu_budget(0) == 0
     with ops.concurrent_streams(2):
         assert ops._cu_budget(0) == 128
-        with ops.concurrent_streams(4):
-            assert ops._cu_budget(0) == 64
+        with ops.concurrent_streams(4):                 # nested regions multiply: 2 x 4 concurrent recurrences
+            assert ops._cu_budget(0) == 32
         assert ops._cu_budget(0) == 128
     assert ops._cu_budget(0) == 0
     ops.set_device_sharers(2)
