@@ -539,13 +539,14 @@ extern "C" int laed_gru_bwd_cus(const float* x, const float* w_ih, const float* 
     // dW_ih[3H][E] = dgi^T[3H][TB] x[TB][E] ; db_ih = colsum(dgi)
     LAED_TRY(laed_sgemm_splitk_impl(true, false, 3 * H, E, TB, gates, 3 * H, x, E, dw_ih, E, nullptr, acc, db_ih, acc,
                                     ws, ws_floats, false, nullptr, stream));
-    // dx[TB][E] = dgi[TB][3H] W_ih[3H][E]
+    // dx[TB][E] = dgi[TB][3H] W_ih[3H][E]   (E = 200 wide: 76 blocks of 64x64 at the reference's batch of 30 -- K may split)
     if (dx != nullptr) {
         if (xmode) {
             LAED_TRY(laed_transpose_impl(w_ih, E, 3 * H, E, WihT, 3 * H, stream));
             LAED_TRY(laed_sgemm_impl(false, true, TB, E, 3 * H, gates, 3 * H, WihT, 3 * H, dx, E, nullptr, false, nullptr, false, stream));
         } else {
-            LAED_TRY(laed_sgemm_impl(false, false, TB, E, 3 * H, gates, 3 * H, w_ih, E, dx, E, nullptr, false, nullptr, false, stream));
+            LAED_TRY(laed_sgemm_splitk_impl(false, false, TB, E, 3 * H, gates, 3 * H, w_ih, E, dx, E, nullptr, false, nullptr, false,
+                                            ws, ws_floats, false, nullptr, stream));
         }
     }
     return 0;

@@ -99,10 +99,14 @@ inline int rows_grid(int64_t rows) { return (int)(rows < 4096 ? (rows < 1 ? 1 : 
 
 }   // namespace
 
-// floats of workspace: forward needs one [chunk_rows][ldl] tile, backward two
+// floats of workspace: forward needs one [chunk_rows][ldl] tile, backward two; whatever the caller passes beyond the
+// tiles holds split-K partials of the products whose output is small and whose K is long (P Wemb and dh = dP W: 76-80
+// blocks of 64x64 with K = V at the reference's batch of 30 -- 340 / 166 us unsplit).  This function asks for up to one
+// more tile (capped at 256 MB) for them; a call that passes the bare tiles still works, unsplit.
 extern "C" int64_t laed_softmax_embed_workspace(int V, int chunk_rows, int backward) {
     const int64_t ldl = laed_proj_nll_ldl(V);
-    return (int64_t)chunk_rows * ldl * (backward ? 2 : 1);
+    const int64_t tile = (int64_t)chunk_rows * ldl, cap = (int64_t)1 << 26;
+    return tile * (backward ? 2 : 1) + (tile < cap ? tile : cap);
 }
 
 extern "C" int laed_softmax_embed_fwd(const float* h, const float* W, const float* b, const float* Wemb,
@@ -113,15 +117,18 @@ extern "C" int laed_softmax_embed_fwd(const float* h, const float* W, const floa
     if (N == 0) return 0;
     LAED_CHECK_ARG(h && W && Wemb && workspace && lse && out, "softmax_embed_fwd: null pointer");
     LAED_CHECK_ARG(aligned16(workspace), "softmax_embed_fwd: workspace must be 16-byte aligned");
-    LAED_CHECK_ARG(ws_floats >= laed_softmax_embed_workspace(V, chunk_rows, 0), "softmax_embed_fwd: workspace too small");
     const int64_t ldl = laed_proj_nll_ldl(V);
+    LAED_CHECK_ARG(ws_floats >= (int64_t)chunk_rows * ldl, "softmax_embed_fwd: workspace too small");
+    float* sk = workspace + (int64_t)chunk_rows * ldl;               // split-K partials (may be empty)
+    const int64_t sk_floats = ws_floats - (int64_t)chunk_rows * ldl;
     for (int64_t r0 = 0; r0 < N; r0 += chunk_rows) {
         const int rows = (int)((N - r0) < chunk_rows ? (N - r0) : chunk_rows);
         LAED_TRY(laed_sgemm_impl(false, true, rows, V, H, h + r0 * H, H, W, H, workspace, ldl, b, false, nullptr, false, stream));
         hipLaunchKernelGGL((softmax_rows_kernel<false>), dim3(rows_grid(rows)), dim3(256), 0, stream, workspace, (int64_t)rows, V,
                            ldl, lse + r0);
         LAED_LAUNCH_CHECK("softmax_rows");
-        LAED_TRY(laed_sgemm_impl(false, false, rows, E, V, workspace, ldl, Wemb, E, out + r0 * E, E, nullptr, false, nullptr, false, stream));
+        LAED_TRY(laed_sgemm_splitk_impl(false, false, rows, E, V, workspace, ldl, Wemb, E, out + r0 * E, E, nullptr, false, nullptr,
+                                        false, sk_floats > 0 ? sk : nullptr, sk_floats, false, nullptr, stream));
     }
     return 0;
 }
@@ -135,10 +142,12 @@ extern "C" int laed_softmax_embed_bwd(const float* h, const float* W, const floa
     if (N == 0) return 0;
     LAED_CHECK_ARG(h && W && Wemb && lse && dout && workspace && dh && dW && db && dWemb, "softmax_embed_bwd: null pointer");
     LAED_CHECK_ARG(aligned16(workspace), "softmax_embed_bwd: workspace must be 16-byte aligned");
-    LAED_CHECK_ARG(ws_floats >= laed_softmax_embed_workspace(V, chunk_rows, 1), "softmax_embed_bwd: workspace too small");
     const int64_t ldl = laed_proj_nll_ldl(V);
+    LAED_CHECK_ARG(ws_floats >= 2 * (int64_t)chunk_rows * ldl, "softmax_embed_bwd: workspace too small");
     float* P = workspace;
     float* dP = workspace + (int64_t)chunk_rows * ldl;
+    const int64_t sk_floats = ws_floats - 2 * (int64_t)chunk_rows * ldl;
+    float* sk = sk_floats > 0 ? workspace + 2 * (int64_t)chunk_rows * ldl : nullptr;    // split-K partials, consumed in stream order
     bool acc = accumulate_w != 0;
     for (int64_t r0 = 0; r0 < N; r0 += chunk_rows) {
         const int rows = (int)((N - r0) < chunk_rows ? (N - r0) : chunk_rows);
@@ -149,13 +158,16 @@ extern "C" int laed_softmax_embed_bwd(const float* h, const float* W, const floa
                            const_cast<float*>(lse) + r0);
         LAED_LAUNCH_CHECK("softmax_rows");
         // dWemb[V][E] (+)= P^T[V][rows] dout_c[rows][E]
-        LAED_TRY(laed_sgemm_impl(true, false, V, E, rows, P, ldl, dc, E, dWemb, E, nullptr, acc, nullptr, false, stream));
+        LAED_TRY(laed_sgemm_splitk_impl(true, false, V, E, rows, P, ldl, dc, E, dWemb, E, nullptr, acc, nullptr, false, sk, sk_floats,
+                                        false, nullptr, stream));
         // dP[rows][V] = dout_c[rows][E] Wemb^T   (Wemb [V][E] is the K-contiguous "W" of an x W^T product)
         LAED_TRY(laed_sgemm_impl(false, true, rows, V, E, dc, E, Wemb, E, dP, ldl, nullptr, false, nullptr, false, stream));
         hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(rows_grid(rows)), dim3(256), 0, stream, P, dP, (int64_t)rows, V, ldl);
         LAED_LAUNCH_CHECK("softmax_bwd_rows");
-        LAED_TRY(laed_sgemm_impl(false, false, rows, H, V, P, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr, false, stream));
-        LAED_TRY(laed_sgemm_impl(true, false, V, H, rows, P, ldl, hc, H, dW, H, nullptr, acc, db, acc, stream));
+        LAED_TRY(laed_sgemm_splitk_impl(false, false, rows, H, V, P, ldl, W, H, dh + r0 * H, H, nullptr, false, nullptr, false, sk,
+                                        sk_floats, false, nullptr, stream));
+        LAED_TRY(laed_sgemm_splitk_impl(true, false, V, H, rows, P, ldl, hc, H, dW, H, nullptr, acc, db, acc, sk, sk_floats, false,
+                                        nullptr, stream));
         acc = true;
     }
     return 0;

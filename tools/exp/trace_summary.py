@@ -11,3 +11,14 @@ for r in rows:
     k=r['Kernel_Name'][:70]; d[k][0]+=1; d[k][1]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
 for k,(c,t) in sorted(d.items(),key=lambda x:-x[1][1])[:25]:
     print("%-70s %7.1f/step %8.3f ms/step %6.1f us"%(k,c/steps,t/1e6/steps,t/1e3/c))
+
+# the GEMM launches by grid: (kernel, Grid_Size_X/Y/Z) -> count and mean duration
+if "--grids" in sys.argv:
+    gd = defaultdict(lambda: [0, 0])
+    for r in rows:
+        if "sgemm_kernel" not in r['Kernel_Name'] and "--all" not in sys.argv:
+            continue
+        k = (r['Kernel_Name'][35:95] if 'sgemm_kernel' in r['Kernel_Name'] else r['Kernel_Name'][:60], r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Grid_Size_Y', ''), r.get('Grid_Size_Z', ''))
+        gd[k][0] += 1; gd[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    for k, (c, t) in sorted(gd.items(), key=lambda x: -x[1][1])[:40]:
+        print("%-60s grid %6s %4s %3s  %6.2f/step %7.1f us  %7.3f ms/step" % (k[0], k[1], k[2], k[3], c / steps, t / 1e3 / c, t / 1e6 / steps))
