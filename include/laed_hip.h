@@ -230,7 +230,9 @@ int laed_proj_nll(const float* h, const float* W, const float* b, const int64_t*
  * [chunk_rows][ldl] workspace tile (two tiles in backward, which recomputes the logits from h).
  *   fwd: lse[N] (saved for backward), out[N][E]
  *   bwd: dout[N][E] -> dh[N][H], dW[V][H] (+)=, db[V] (+)=, dWemb[V][E] (+)=   ((+)= if accumulate_w)
- *   workspace: laed_softmax_embed_workspace(V, chunk_rows, backward) floats
+ *   workspace: laed_softmax_embed_workspace(V, chunk_rows, backward) floats = the tiles plus up to one more tile (at most
+ *   2^26 floats) of split-K scratch for the long-K products with few output tiles (P Wemb, dP W); the calls accept any
+ *   size from the bare tiles up and split K only as far as the surplus allows
  * ------------------------------------------------------------------------------------------ */
 int64_t laed_softmax_embed_workspace(int V, int chunk_rows, int backward);
 int laed_softmax_embed_fwd(const float* h, const float* W, const float* b, const float* Wemb,
