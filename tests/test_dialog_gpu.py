@@ -173,13 +173,16 @@ def test_dialog_model_eval_and_greedy_vs_reference(name):
     assert np.array_equal(labels.cpu().numpy(), G["gen/labels"])
 
 
-def test_softmax_embed_kernel_vs_torch():
-    """laed_softmax_embed_{fwd,bwd} through the C ABI vs fp64 torch-CPU math, odd sizes, several row chunks."""
+@pytest.mark.parametrize("N,H,V,E,chunk,bare", [(300, 40, 1003, 24, 128, False),
+                                                (1170, 256, 10004, 200, 1170, False),    # AE-ED / ST-ED at B = 30: K = V splits
+                                                (1170, 256, 10004, 200, 600, True)])     # bare tiles: the unsplit products
+def test_softmax_embed_kernel_vs_torch(N, H, V, E, chunk, bare):
+    """laed_softmax_embed_{fwd,bwd} through the C ABI vs fp64 torch-CPU math: odd sizes with several row chunks, and the
+    reference's batch shape with and without the split-K surplus in the workspace."""
     import ctypes
     from laed_amd import ops
     from laed_amd._lib import check, lib, ptr, stream
     rs = np.random.RandomState(5)
-    N, H, V, E = 300, 40, 1003, 24
     h = rs.randn(N, H).astype(np.float32)
     W = (rs.randn(V, H) * 0.3).astype(np.float32)
     b = rs.randn(V).astype(np.float32)
@@ -189,8 +192,11 @@ def test_softmax_embed_kernel_vs_torch():
     ref = torch.softmax(t["h"] @ t["W"].t() + t["b"], dim=1) @ t["We"]
     ref.backward(torch.tensor(dout, dtype=torch.float64))
     d = {k: torch.from_numpy(v).cuda() for k, v in dict(h=h, W=W, b=b, We=We, dout=dout).items()}
-    chunk = 128
     ws_n = int(lib.laed_softmax_embed_workspace(V, chunk, 1))
+    ldl = int(lib.laed_proj_nll_ldl(V))
+    assert ws_n > 2 * chunk * ldl
+    if bare:
+        ws_n = 2 * chunk * ldl
     ws = torch.empty(ws_n, device="cuda")
     lse, out = torch.empty(N, device="cuda"), torch.empty((N, E), device="cuda")
     check(lib.laed_softmax_embed_fwd(ptr(d["h"]), ptr(d["W"]), ptr(d["b"]), ptr(d["We"]), N, H, V, E, ptr(ws), ws_n, chunk,
