@@ -307,28 +307,35 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
         const float4* src = reinterpret_cast<const float4*>(p.wp + (int64_t)blockIdx.x * H * NC);
         for (int i = tid; i < (H / 4) * NC; i += NTH) reinterpret_cast<float4*>(slab)[(i / NC) * WS4 + i % NC] = src[i];
     }
+    // row groups (blockIdx.y): the sequences of a batch are independent, so each group of BP rows is a recurrence of its
+    // own -- own ping-pong operand, own arrival counter -- and a workgroup reads only its group's rows of h_{t-1}
+    const int grp = blockIdx.y;
     const int row = tid / UF, u = tid % UF, j = j0 + u;
-    const bool mine = row < B;
+    const int grow = grp * BP + row;
+    const bool mine = row < BP && grow < B;
     float hp = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f;
     if (mine) {
-        hp = p.hbuf[(int64_t)row * H + j];
+        hp = p.hbuf[(int64_t)grow * H + j];
         bhr = p.b_hh[j]; bhz = p.b_hh[H + j]; bhn = p.b_hh[2 * H + j];
     }
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(p.hx0, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(p.hx1, 0, 0x7fffffff, 0x00020000);
+    float* const hx0 = p.hx0 + (int64_t)grp * H * BP;
+    float* const hx1 = p.hx1 + (int64_t)grp * H * BP;
+    unsigned* const cnt = p.sync + 32 * grp;         // one 128-byte line per group; sync[1] stays the shared timeout flag
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(hx0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 0x7fffffff, 0x00020000);
     const unsigned G = gridDim.x;
     bool dead = false;                               // set (per workgroup, via LDS) once a wait has timed out
     __shared__ unsigned s_dead;
     if (tid == 0) s_dead = 0;
     __syncthreads();
     for (int t = 0; t < p.T; ++t) {
-        float* g = p.gates + ((int64_t)t * B + row) * 3 * H;
+        float* g = p.gates + ((int64_t)t * B + grow) * 3 * H;
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
         if (mine) { gi_r = g[j]; gi_z = g[H + j]; gi_n = g[2 * H + j]; }
         if (t > 0) {                                 // every workgroup's slice of h_{t-1} must have been published
             if (tid == 0 && !dead) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)t) {
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)t) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > SPIN_LIMIT) {
                         __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -362,18 +369,18 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
                 h = (1.0f - z) * n + z * hp;
                 if (dead) h = __builtin_nanf("");         // a timed-out wait poisons the output: loud, not silently stale
                 hp = h;
-                p.hbuf[((int64_t)(t + 1) * B + row) * H + j] = h;
+                p.hbuf[((int64_t)(t + 1) * B + grow) * H + j] = h;
                 if (p.hn != nullptr) {
                     g[j] = r; g[H + j] = z; g[2 * H + j] = n;
-                    p.hn[((int64_t)t * B + row) * H + j] = ghn;
+                    p.hn[((int64_t)t * B + grow) * H + j] = ghn;
                 }
             }
-            float* hx_out = (t & 1) ? p.hx0 : p.hx1;
+            float* hx_out = (t & 1) ? hx0 : hx1;
             __hip_atomic_store(hx_out + ((int64_t)(j / 4) * BP + row) * 4 + (j & 3), h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores ...
         __syncthreads();                                           // ... before one lane signals for the workgroup
-        if (tid == 0) __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -407,12 +414,17 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
         const float4* src = reinterpret_cast<const float4*>(p.wpT + (int64_t)blockIdx.x * K * NC);
         for (int i = tid; i < (K / 4) * NC; i += NTH) reinterpret_cast<float4*>(slab)[i] = src[i];
     }
+    const int grp = blockIdx.y;                       // row group: see the forward kernel
     const int row = tid / UB, u = tid % UB, j = j0 + u;
-    const bool mine = row < B;
-    const int64_t i = (int64_t)row * H + j;
+    const int grow = grp * BP + row;
+    const bool mine = row < BP && grow < B;
+    const int64_t i = (int64_t)grow * H + j;
     float carry = mine ? p.dh[i] : 0.f;
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(p.dx0, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(p.dx1, 0, 0x7fffffff, 0x00020000);
+    float* const dx0 = p.dx0 + (int64_t)grp * K * BP;
+    float* const dx1 = p.dx1 + (int64_t)grp * K * BP;
+    unsigned* const cnt = p.sync + 32 * grp;
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(dx0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(dx1, 0, 0x7fffffff, 0x00020000);
     const unsigned G = gridDim.x;
     bool dead = false;
     __shared__ unsigned s_dead;
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
         const int t = p.T - 1 - s;                   // t = -1: the closing step
         const bool fin = t < 0;
         float dh = carry, r = 0.f, z = 0.f, nn = 0.f, hnv = 0.f, hp = 0.f;
-        float* g = fin ? nullptr : p.gates + ((int64_t)t * B + row) * 3 * H;
+        float* g = fin ? nullptr : p.gates + ((int64_t)t * B + grow) * 3 * H;
         if (mine && !fin) {
             const int64_t it = (int64_t)t * B * H + i;
             if (p.dout != nullptr) dh += p.dout[it];
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
         if (s > 0) {                                 // every workgroup's slice of dgh_{t+1} must have been published
             if (tid == 0 && !dead) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)s) {
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)s) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > SPIN_LIMIT) {
                         __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
         if (row < BP) {
             float drp = 0.f, dzp = 0.f, dnr = 0.f;
             if (mine) {
-                float* d = p.dgh + ((int64_t)t * B + row) * 3 * H;
+                float* d = p.dgh + ((int64_t)t * B + grow) * 3 * H;
                 const float dn = dh * (1.0f - z);
                 const float dz = dh * (hp - nn);
                 const float dnp = dn * (1.0f - nn * nn);
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
                 d[j] = drp; d[H + j] = dzp; d[2 * H + j] = dnr;
                 carry = dh * z;
             }
-            float* dx_out = (s & 1) ? p.dx1 : p.dx0;
+            float* dx_out = (s & 1) ? dx1 : dx0;
             const int e4 = j & 3;
             __hip_atomic_store(dx_out + ((int64_t)(j / 4) * BP + row) * 4 + e4, drp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dx_out + ((int64_t)((H + j) / 4) * BP + row) * 4 + e4, dzp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -579,7 +591,12 @@ extern "C" int laed_gru_persist_timeouts(unsigned* out_host) {
 
 // Row groups: up to 64 rows one group (padded to whole 16-row MFMA tiles); larger batches run as groups of 64 rows in
 // blockIdx.y of the per-step kernels, each group re-reading the packed W_hh out of L2.
-static int small_groups(int B) { return B <= 64 ? 1 : (B + 63) / 64; }
+static int mid_rows() {      // rows per group of a mid-size batch (experiment hook LAED_GRU_MID_ROWS = 16 / 32 / 64)
+    static const int v = []() { const char* e = laed_exp_hook("LAED_GRU_MID_ROWS"); const int r = e ? atoi(e) : 64;
+                                return (r == 16 || r == 32 || r == 64) ? r : 64; }();
+    return v;
+}
+static int small_groups(int B) { return B <= 64 ? 1 : (B + mid_rows() - 1) / mid_rows(); }
 
 // H a multiple of 16 (quads, whole MFMA k-groups, whole unit slices) and
 //   B <= 64: the reference's own batch sizes (persistent launches), or
@@ -593,35 +610,63 @@ bool laed_gru_small_ok(int B, int H) {
     return mid && B <= 512 && (int64_t)small_groups(B) * 3 * H * H * 4 <= ((int64_t)32 << 20);
 }
 
-int laed_gru_small_bp(int B) { return B <= 64 ? (B + 15) / 16 * 16 : 64; }
+int laed_gru_small_bp(int B) { return B <= 64 ? (B + 15) / 16 * 16 : mid_rows(); }
+
+// Row groups of the PERSISTENT launches (B <= 64): the batch is cut into groups of 16 or 32 rows while all their
+// workgroups (grid_x per group, one per CU) still fit the CUs this call may count on -- every workgroup then pulls only
+// its group's rows of the previous step's operand across the fabric, which is what a step of these kernels waits for
+// (one group: 4.9 / 6.75 us per forward / backward step at B = 30, 8.3 / 11.1 us at B = 60, H = 512 -- the time follows the
+// rows; grouped: DI-VAE step at B = 30 1.99 -> 1.78 ms, DI-VST at B = 60 3.82 -> 3.33 ms, losses bit-identical).
+// LAED_GRU_PGROUPS=0 (hooks build) keeps one group.
+struct PersistGroups { int rows, groups; };
+static PersistGroups persist_groups(int B, int grid_x, int cu_limit) {
+    static const bool on = []() { const char* e = laed_exp_hook("LAED_GRU_PGROUPS"); return !(e != nullptr && atoi(e) == 0); }();
+    const int bp = laed_gru_small_bp(B);
+    if (on && B <= 64) {
+        for (int rows = 16; rows < bp; rows += 16) {
+            const int groups = (B + rows - 1) / rows;
+            if (rows != 48 && (int64_t)groups * grid_x <= cu_limit) return {rows, groups};
+        }
+    }
+    return {bp, 1};
+}
+// padded rows of the quad-major operands: the persistent grouping above may pad B up to 4 x 16 or 2 x 32 rows
+static int small_ws_rows(int B) { return B <= 64 ? 64 : laed_gru_small_bp(B) * small_groups(B); }
 
 int64_t laed_gru_small_fwd_ws(int B, int H) {
-    return (int64_t)3 * H * H + (int64_t)2 * H * laed_gru_small_bp(B) * small_groups(B) + 64;
+    return (int64_t)3 * H * H + (int64_t)2 * H * small_ws_rows(B) + 160;
 }
 int64_t laed_gru_small_bwd_ws(int B, int H) {
-    return (int64_t)3 * H * H + (int64_t)2 * 3 * H * laed_gru_small_bp(B) * small_groups(B) + 64;
+    return (int64_t)3 * H * H + (int64_t)2 * 3 * H * small_ws_rows(B) + 160;
 }
 
 // forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
 int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
                        float* ws, int cu_budget, hipStream_t stream) {
-    const int BP = laed_gru_small_bp(B), NG = small_groups(B);
+    int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wp = ws;
-    float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP * NG};
     hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wp);
     LAED_LAUNCH_CHECK("gru_small pack_w_fwd");
-    hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32 * NG), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, NG, hx[0]);
-    LAED_LAUNCH_CHECK("gru_small rows_to_quads");
     // default: one persistent launch with LDS-resident W_hh (4.9 vs 6.3 us per step + launch gaps at B = 30, H = 512);
     // LAED_GRU_PERSIST=0 selects the per-step launches below
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
     // every workgroup of the persistent grid must be resident at once, one per CU: take that path only when the grid
     // fits the CUs this call may count on (the device's CU count, or the caller's share of it when a second stream
     // may hold a persistent grid of its own at the same time)
-    if (persist && NG == 1 && H / UF <= laed_persist_cu_limit(cu_budget)) {
-        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP);
-        hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
+    const int cu_limit = laed_persist_cu_limit(cu_budget);
+    const bool persistent = persist && NG == 1 && H / UF <= cu_limit;
+    if (persistent) {
+        const PersistGroups pg = persist_groups(B, H / UF, cu_limit);
+        BP = pg.rows;
+        NG = pg.groups;
+    }
+    float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP * NG};
+    hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32 * NG), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, NG, hx[0]);
+    LAED_LAUNCH_CHECK("gru_small rows_to_quads");
+    if (persistent) {
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP * NG);
+        hipError_t e = hipMemsetAsync(sync, 0, 160 * sizeof(float), stream);      // a 128-byte line per group (<= 4) + the flag
         if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
         PersistFwdArgs a;
         a.hx0 = hx[0]; a.hx1 = hx[1]; a.wp = wp; a.b_hh = b_hh; a.hbuf = hbuf; a.gates = gates; a.hn = hn; a.sync = sync;
@@ -632,13 +677,13 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
         auto go = [&](auto kern) -> int {
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e2 != hipSuccess) return laed_fail((int)e2, "gru_small: hipFuncSetAttribute failed");
-            hipLaunchKernelGGL(kern, dim3(H / UF), dim3(NTH), lds, stream, a);
+            hipLaunchKernelGGL(kern, dim3(H / UF, NG), dim3(NTH), lds, stream, a);
             return 0;
         };
         int st;
-        if (B <= 16) st = go(gru_small_persist_fwd_kernel<1>);
-        else if (B <= 32) st = go(gru_small_persist_fwd_kernel<2>);
-        else if (B <= 48) st = go(gru_small_persist_fwd_kernel<3>);
+        if (BP <= 16) st = go(gru_small_persist_fwd_kernel<1>);
+        else if (BP <= 32) st = go(gru_small_persist_fwd_kernel<2>);
+        else if (BP <= 48) st = go(gru_small_persist_fwd_kernel<3>);
         else st = go(gru_small_persist_fwd_kernel<4>);
         if (st != 0) return st;
         LAED_LAUNCH_CHECK("gru_small_persist_fwd");
@@ -650,7 +695,7 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
         a.gates = gates + (int64_t)t * B * 3 * H; a.hout = hbuf + (int64_t)(t + 1) * BH;
         a.hn = hn ? hn + (int64_t)t * BH : nullptr; a.hx_out = hx[(t + 1) & 1];
         a.B = B; a.H = H; a.nkw = k_waves(H);
-        launch_rt(B, dim3(H / UF, NG), stream, a, gru_small_fwd_kernel<1>, gru_small_fwd_kernel<2>, gru_small_fwd_kernel<3>,
+        launch_rt(BP, dim3(H / UF, NG), stream, a, gru_small_fwd_kernel<1>, gru_small_fwd_kernel<2>, gru_small_fwd_kernel<3>,
                   gru_small_fwd_kernel<4>);
         LAED_LAUNCH_CHECK("gru_small_fwd");
     }
@@ -664,36 +709,40 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
     const int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wpT = ws;
-    float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP * NG};
     hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT);
     LAED_LAUNCH_CHECK("gru_small pack_w_bwd");
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
-    if (persist && NG == 1 && H / UB <= laed_persist_cu_limit(cu_budget)) {
-        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * BP);
-        hipError_t e = hipMemsetAsync(sync, 0, 64 * sizeof(float), stream);
+    const int cu_limit = laed_persist_cu_limit(cu_budget);
+    if (persist && NG == 1 && H / UB <= cu_limit) {
+        const PersistGroups pg = persist_groups(B, H / UB, cu_limit);
+        const int PBP = pg.rows, PG = pg.groups;
+        float* pdx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * PBP * PG};
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * PBP * PG);
+        hipError_t e = hipMemsetAsync(sync, 0, 160 * sizeof(float), stream);      // a 128-byte line per group (<= 4) + the flag
         if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
         PersistBwdArgs a;
-        a.dx0 = dx[0]; a.dx1 = dx[1]; a.wpT = wpT; a.dout = dout; a.hbuf = hbuf; a.hn = hn; a.gates = gates; a.dgh = dgh;
+        a.dx0 = pdx[0]; a.dx1 = pdx[1]; a.wpT = wpT; a.dout = dout; a.hbuf = hbuf; a.hn = hn; a.gates = gates; a.dgh = dgh;
         a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H);
-        size_t lds = ((size_t)3 * H * UB + (size_t)NW * BP * UB) * sizeof(float);
+        size_t lds = ((size_t)3 * H * UB + (size_t)NW * PBP * UB) * sizeof(float);
         if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU
         if (lds <= 160 * 1024) {
             auto go = [&](auto kern) -> int {
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e2 != hipSuccess) return laed_fail((int)e2, "gru_small: hipFuncSetAttribute failed");
-                hipLaunchKernelGGL(kern, dim3(H / UB), dim3(NTH), lds, stream, a);
+                hipLaunchKernelGGL(kern, dim3(H / UB, PG), dim3(NTH), lds, stream, a);
                 return 0;
             };
             int st;
-            if (B <= 16) st = go(gru_small_persist_bwd_kernel<1>);
-            else if (B <= 32) st = go(gru_small_persist_bwd_kernel<2>);
-            else if (B <= 48) st = go(gru_small_persist_bwd_kernel<3>);
+            if (PBP <= 16) st = go(gru_small_persist_bwd_kernel<1>);
+            else if (PBP <= 32) st = go(gru_small_persist_bwd_kernel<2>);
+            else if (PBP <= 48) st = go(gru_small_persist_bwd_kernel<3>);
             else st = go(gru_small_persist_bwd_kernel<4>);
             if (st != 0) return st;
             LAED_LAUNCH_CHECK("gru_small_persist_bwd");
             return 0;
         }
     }
+    float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP * NG};
     for (int t = T - 1; t >= -1; --t) {
         SmallBwdArgs a;
         const bool fin = t < 0;
@@ -706,7 +755,7 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
         a.dgh = fin ? nullptr : dgh + (int64_t)t * B * 3 * H;
         a.dx_out = fin ? nullptr : dx[t & 1];
         a.dh = dh0; a.B = B; a.H = H; a.nkw = k_waves(3 * H); a.final_step = fin ? 1 : 0;
-        launch_rt(B, dim3(H / UB, NG), stream, a, gru_small_bwd_kernel<1>, gru_small_bwd_kernel<2>, gru_small_bwd_kernel<3>,
+        launch_rt(BP, dim3(H / UB, NG), stream, a, gru_small_bwd_kernel<1>, gru_small_bwd_kernel<2>, gru_small_bwd_kernel<3>,
                   gru_small_bwd_kernel<4>);
         LAED_LAUNCH_CHECK("gru_small_bwd");
     }
