@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """DI-VAE train-step benchmark on MI355X (BASELINE.json: train tokens/s, whole node; fwd+bwd step ms).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # any N: for N > 1 (and no RANK in the environment) this
+                                                           # process starts the N ranks itself and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the driver's own launcher form: used as given
 
 Workload "S-fixed" (BASELINE.json configs[4]): DI-VAE, V=50000, E=200, H_enc=H_dec=1024, y=20, k=10,
 T=40, GLOBAL batch 4096 (strong scaling: 4096/N sequences per GPU), every row [<s>, Zipf ids..., </s>], fp32,
@@ -169,6 +170,39 @@ def cpu_baseline(V, E, H, y, k, T, sample_b, steps=2, warmup=1):
     return sample_b * (T - 1) / dt, dt
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as FRESH processes (torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU call -- it never makes one: a process
+    that has initialised the GPU must not be replaced or forked on this pool -- and relay rank 0's single JSON line.
+    The ranks' stderr passes through; their other stdout lines (launcher / gloo chatter) go to stderr.  One attempt
+    only: a failed GPU run is read, not repeated.  Returns the exit code for this process."""
+    import socket
+    import subprocess
+    probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    probe.bind(("127.0.0.1", 0))                             # a free port for rank 0's store
+    port = probe.getsockname()[1]
+    probe.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this host driver
+    env["LAED_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+        return rc
+    print("bench.py: the %d ranks ended (rc %d) without a result line" % (n, rc), file=sys.stderr)
+    return rc or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,12 +230,13 @@ def main():
     if os.environ.get("LAED_BENCH_WATCHDOG"):                # seconds: dump every thread's stack and exit (hang diagnosis)
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["LAED_BENCH_WATCHDOG"]), exit=True)
+    if args.gpus > 1 and "RANK" not in os.environ:           # no launcher around us: be the launcher (no GPU call yet)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
-                         % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     ndev = torch.cuda.device_count()
@@ -404,6 +439,13 @@ def main():
             "encoder_tokens_per_s": main_res["encoder_tokens_per_s"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == "fp32" else "f32 (x W^T products as split-bf16 bf16x3, fp32 accumulate)",
             "data": "synthetic",
+            # what actually carried the exchanges: torch.distributed's group as initialised, not the flag
+            "backend": (("rccl" if str(dist.get_backend()).lower() == "nccl" else str(dist.get_backend()).lower())
+                        if dist.is_initialized() else None),
+            "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and str(dist.get_backend()).lower() == "nccl")
+                           else 0),
+            "launched_by": ("bench.py (self-launched torch.distributed.run)" if os.environ.get("LAED_BENCH_SELF_LAUNCHED")
+                            else "external launcher" if "RANK" in os.environ else "single process"),
             **({"rehearsal": "backend gloo, %d ranks on %d GPU(s): exercises the N>1 code path (sharding, forward "
                              "exchanges, bucketed gradient all-reduce); NOT a scaling number" % (world, ndev)}
                if (world > 1 and args.backend == "gloo") else {}),

@@ -130,6 +130,10 @@ int laed_gru_bwd_cus(const float* x, const float* w_ih, const float* w_hh,
                      float* dgh, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                      float* dh0, int accumulate_w, float* ws, int64_t ws_floats, int cu_budget, void* stream);
 int laed_gru_persist_timeouts(unsigned* out_host);
+/* Persistent launches this process has issued so far (host-side counters, no device access): which path a call took
+ * is otherwise invisible -- a CU budget, a sharer count or a grid that does not fit silently selects the per-step
+ * launches.  No counterpart in the reference (nn.GRU hides its algorithm choice the same way). */
+int laed_gru_persist_launches(unsigned* fwd_host, unsigned* bwd_host);
 
 /* ------------------------------------------------------------------------------------------
  * Posterior / Gumbel-softmax latent (rows R = B*y_size, k classes, k <= 64).

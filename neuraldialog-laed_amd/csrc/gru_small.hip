@@ -23,6 +23,7 @@
 #include "laed_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -589,6 +590,17 @@ extern "C" int laed_gru_persist_timeouts(unsigned* out_host) {
     return 0;
 }
 
+// Persistent launches issued by this process (host-side counters: [0] forward, [1] backward).  Tests and the engine
+// read them to know WHICH recurrence path a call took (a CU budget, a sharer count or a grid that does not fit sends
+// a call to the per-step launches without any other visible sign).
+static std::atomic<unsigned> g_persist_launches[2];
+extern "C" int laed_gru_persist_launches(unsigned* fwd_host, unsigned* bwd_host) {
+    LAED_CHECK_ARG(fwd_host != nullptr && bwd_host != nullptr, "gru_persist_launches: null pointer");
+    *fwd_host = g_persist_launches[0].load();
+    *bwd_host = g_persist_launches[1].load();
+    return 0;
+}
+
 // Row groups: up to 64 rows one group (padded to whole 16-row MFMA tiles); larger batches run as groups of 64 rows in
 // blockIdx.y of the per-step kernels, each group re-reading the packed W_hh out of L2.
 static int mid_rows() {      // rows per group of a mid-size batch (experiment hook LAED_GRU_MID_ROWS = 16 / 32 / 64)
@@ -687,6 +699,7 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
         else st = go(gru_small_persist_fwd_kernel<4>);
         if (st != 0) return st;
         LAED_LAUNCH_CHECK("gru_small_persist_fwd");
+        g_persist_launches[0].fetch_add(1);
         return 0;
     }
     for (int t = 0; t < T; ++t) {
@@ -739,6 +752,7 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
             else st = go(gru_small_persist_bwd_kernel<4>);
             if (st != 0) return st;
             LAED_LAUNCH_CHECK("gru_small_persist_bwd");
+            g_persist_launches[1].fetch_add(1);
             return 0;
         }
     }

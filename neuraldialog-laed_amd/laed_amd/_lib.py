@@ -35,6 +35,7 @@ _SIGS = {
     "laed_gru_fwd_cus": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p], _i),
     "laed_gru_bwd_cus": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _p], _i),
     "laed_gru_persist_timeouts": ([ctypes.POINTER(ctypes.c_uint)], _i),
+    "laed_gru_persist_launches": ([ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)], _i),
     "laed_gru_fwd_workspace": ([_i, _i, _i, _i], _i64),
     "laed_gru_bwd": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _p], _i),
     "laed_gru_bwd_workspace": ([_i, _i, _i, _i], _i64),

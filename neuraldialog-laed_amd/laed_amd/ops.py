@@ -397,6 +397,14 @@ def gru_persist_timeouts():
     return int(out.value)
 
 
+def gru_persist_launches():
+    """(forward, backward) persistent-recurrence launches this process has issued so far (host counters)."""
+    import ctypes
+    f, b = ctypes.c_uint(0), ctypes.c_uint(0)
+    check(lib.laed_gru_persist_launches(ctypes.byref(f), ctypes.byref(b)), "laed_gru_persist_launches")
+    return int(f.value), int(b.value)
+
+
 class GRUFunction(torch.autograd.Function):
     """x[T,B,E] (time-major) -> out[T,B,H], hT[B,H]."""
 

@@ -41,3 +41,44 @@ def test_script_default_configs():
     ae, st = bench.make_dialog_config(200, 512, 3, 5, 40, 30, False), bench.make_dialog_config(200, 512, 3, 5, 40, 30, True)
     assert (ae.utt_type, ae.freeze_step, ae.backward_size, ae.utt_cell_size) == ('attn_rnn', 4000, 30, 256)
     assert (st.utt_type, st.freeze_step, st.backward_size) == ('rnn', 5000, 10)
+
+
+def test_gpus_n_self_launches_its_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` with no launcher around it (no RANK in the environment) starts N fresh ranks through
+    torch.distributed.run on 127.0.0.1 and relays rank 0's single JSON line; other stdout chatter goes to stderr."""
+    import io
+    import subprocess
+    seen = {}
+
+    class FakeProc(object):
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["env"] = cmd, kw["env"]
+            self.stdout = io.StringIO('gloo chatter\n{"metric": "train tokens/sec (DI-VAE, whole node)", "n_gpus": 2}\n')
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("RANK", raising=False)
+    rc = bench.self_launch(2, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo"])
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-9] == os.path.abspath(bench.__file__) and cmd[-8:-6] == ["--gpus", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["LAED_BENCH_SELF_LAUNCHED"] == "1"
+    cap = capsys.readouterr()
+    assert cap.out.strip().splitlines() == ['{"metric": "train tokens/sec (DI-VAE, whole node)", "n_gpus": 2}']
+    assert "gloo chatter" in cap.err
+
+
+def test_gpus_n_spawn_reaches_real_ranks():
+    """The real thing, on this GPU-less container: two ranks are started (each sees WORLD_SIZE=2 and a RANK, so none of
+    them launches again), each refuses to run without an MI355X, and the parent reports the failure instead of a line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--backend", "gloo", "--global-batch", "128",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert r.stderr.count("bench.py needs an MI355X") >= 1
+    assert "without a result line" in r.stderr

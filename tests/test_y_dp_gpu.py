@@ -1,6 +1,7 @@
-"""Data-parallel train step with the real HIP kernels: 2 ranks (both on cuda:0 of the 1-GPU box, gloo transport so
+"""Data-parallel train step with the real HIP kernels: 2 or 4 ranks (all on cuda:0 of a 1-GPU box, gloo transport so
 the test does not need two devices) must reproduce the reference's single-process global-batch loss terms and
-gradients.  On the 8-GPU node the same code path runs with backend "nccl" (RCCL over xGMI), one rank per GPU."""
+gradients.  The RCCL case runs ONE RANK PER GPU THE BOX HAS (backend "nccl" over xGMI): a 1-rank group on the 1-GPU
+box, a real 2/3/4/6-rank group on a multi-GPU node, with no flag to set."""
 import datetime
 import os
 import sys
@@ -30,7 +31,8 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     from laed_amd.models.sent_models import DiVAE, DiVST
 
-    torch.cuda.set_device(0)
+    dev = rank if backend == "nccl" else 0         # RCCL: one rank per GPU; gloo: the ranks share cuda:0
+    torch.cuda.set_device(dev)
     # file:// rendezvous: there is no TCP port to probe, release and hope to get back (the store of the earlier tcp://
     # form was bound by rank 0 AFTER the parent had closed its probe socket), and `timeout` turns a rank that never
     # arrives into an error after 60 s instead of a 30-minute wait inside init_process_group
@@ -38,12 +40,14 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
                 timeout=datetime.timedelta(seconds=60))
     if backend == "nccl":
         os.environ["LAED_DP_FORCE"] = "1"          # keep the hooks / side stream / collectives on for a 1-rank group
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0), **rdzv)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev), **rdzv)
     else:
         dist.init_process_group("gloo", **rdzv)
     parallel.init()
     from laed_amd import ops
-    ops.set_device_sharers(world)                  # the ranks share one GPU here (production: one process per GPU)
+    if backend != "nccl":
+        ops.set_device_sharers(world)              # the ranks share one GPU here (production: one process per GPU)
+    launches0 = ops.gru_persist_launches()
     G = load_golden(kind + "_mid")
     cfg = golden_config(G)
     cfg.use_gpu = True
@@ -84,8 +88,16 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
     torch.cuda.synchronize()
     for n, p in model.named_parameters():
         assert float((p.detach().cpu() - torch.from_numpy(G["p1/" + n])).abs().max()) < 1e-4, n
-    from laed_amd import ops
     assert ops.gru_persist_timeouts() == 0         # no bounded in-kernel wait of the persistent GRU kernels timed out
+    f, b = ops.gru_persist_launches()
+    if backend == "nccl":
+        # one process per GPU: encoder and decoder recurrences (B/world <= 64, H = 128) ran as persistent launches, with
+        # the reducer's RCCL stream beside them, and none of their waits gave up
+        nrec = 2 if kind == "divae" else 3         # encoder + one or two decoders
+        assert f - launches0[0] == nrec and b - launches0[1] == nrec, (f, b, launches0)
+    else:
+        # ranks share the GPU: set_device_sharers(world > 1) sends every recurrence to per-step launches
+        assert (f, b) == launches0 or world == 1, (f, b, launches0)
     assert opt.reducer.collectives < sum(1 for p in model.parameters() if p.grad is not None)     # coalesced buckets
     dist.destroy_process_group()
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
@@ -96,16 +108,27 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
 def test_dp_step_equals_reference_global_batch(tmp_path, world, kind):
     """The mid goldens have 12 sequences: 6 or 3 per rank.  Loss terms, every gradient and the parameters after one Adam
     step must equal the reference's single-process global-batch values whatever the rank count.
-    The ranks share the box's one GPU.  Their persistent GRU grids (H = 128: 32 workgroups forward, 16 backward, one per
-    CU) fit side by side even for 4 ranks x 2 streams (256 CUs), and every in-kernel wait is bounded, so the kernels
-    cannot hold a rank; `ops.gru_persist_timeouts() == 0` checks that no wait gave up."""
+    The ranks share the box's one GPU, so the worker calls `ops.set_device_sharers(world)` and every recurrence runs as
+    per-step launches (processes on one GPU are time-sliced: a grid that spins on its own counters is switched out under
+    the spin); the persistent kernels are NOT exercised here -- the worker asserts that their launch
+    counter did not move.  DP combined with the persistent kernels is what the RCCL case below covers."""
     mp.spawn(_worker, args=(world, str(tmp_path), kind), nprocs=world, join=True)
     assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok%d" % r for r in range(world)]
 
 
-def test_dp_path_on_rccl_single_rank(tmp_path):
-    """The same step with backend "nccl" (RCCL) on a 1-rank group with the data-parallel machinery forced on: the
-    gradient hooks, the reducer's side stream and every collective run through RCCL as they do on the 8-GPU node (a
-    1-GPU box cannot host two RCCL ranks), and the result is still the reference's."""
-    mp.spawn(_worker, args=(1, str(tmp_path), "divae", "nccl"), nprocs=1, join=True)
-    assert [f for f in os.listdir(str(tmp_path)) if f.startswith("ok")] == ["ok0"]
+def _rccl_world(batch=12):
+    """One rank per GPU of the box, reduced to a rank count that divides the mid goldens' 12 sequences."""
+    n = max(1, torch.cuda.device_count())
+    return max(w for w in (1, 2, 3, 4, 6, 12) if w <= n and batch % w == 0)
+
+
+@pytest.mark.parametrize("kind", ["divae", "divst"])
+def test_dp_path_on_rccl_one_rank_per_gpu(tmp_path, kind):
+    """The same step with backend "nccl" (RCCL), one rank per GPU the box has: on the 1-GPU box a 1-rank group with the
+    data-parallel machinery forced on (LAED_DP_FORCE), on a multi-GPU node a real N-rank group over xGMI -- the gradient
+    hooks, the reducer's side stream and every collective run through RCCL, the recurrences take the PERSISTENT kernels
+    (asserted through laed_gru_persist_launches) beside the reducer's stream, no in-kernel wait times out, and losses,
+    gradients and the parameters after one Adam step are still the reference's global-batch values."""
+    world = _rccl_world()
+    mp.spawn(_worker, args=(world, str(tmp_path), kind, "nccl"), nprocs=world, join=True)
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok%d" % r for r in range(world)]
