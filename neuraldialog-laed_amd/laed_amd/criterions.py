@@ -25,7 +25,12 @@ class NLLEntropy(_Loss):
             raise NotImplementedError("keyword-weighted NLL (key_vocab) is outside the DI-VAE/DI-VST hot path")
         self.weight = None
 
-    def _row_scale(self, labels_bf, B, T):
+    def local_count(self, labels_bf):
+        """This rank's non-PAD target count as a 1-element float tensor: the per-rank sum a model folds into its one
+        forward exchange (BatchPriorKL(..., extra=...)) so that 'word' needs no collective of its own."""
+        return (labels_bf != self.padding_idx).sum().float().reshape(1)
+
+    def _row_scale(self, labels_bf, B, T, global_count=None):
         """Per-row loss weights [B,T] (batch-first) for the configured averaging mode."""
         dev = labels_bf.device
         ws = parallel.world_size()
@@ -37,16 +42,21 @@ class NLLEntropy(_Loss):
             word_cnt = torch.sign(labels_bf).sum(dim=1, keepdim=True).float()     # criterions.py:62
             return (1.0 / (word_cnt * (B * ws))).expand(B, T)
         if self.avg_type == 'word':
-            cnt = (labels_bf != self.padding_idx).sum().float().reshape(1)
-            parallel.all_reduce_sum_(cnt)                                         # global non-PAD count
+            if global_count is not None:                                         # already all-reduced by the caller
+                cnt = global_count.reshape(1)
+            else:
+                cnt = self.local_count(labels_bf)
+                parallel.all_reduce_sum_(cnt)                                     # global non-PAD count
             return (1.0 / cnt).expand(B, T)
         raise ValueError("Unknown avg type")
 
-    def forward(self, net_output, labels):
+    def forward(self, net_output, labels, global_count=None):
+        """`global_count` (optional, beyond the reference's signature): the GLOBAL non-PAD target count as a 1-element
+        device tensor when the caller has already exchanged it (data parallelism, 'word' averaging)."""
         from .enc2dec.decoders import LazyLogProbs
         B, T = labels.shape[0], labels.shape[1]
         if isinstance(net_output, LazyLogProbs):
-            scale_tm = self._row_scale(labels, B, T).t().contiguous().view(-1)
+            scale_tm = self._row_scale(labels, B, T, global_count).t().contiguous().view(-1)
             labels_tm = labels.t().contiguous().view(-1)
             loss, tok = ops.ProjNLLFunction.apply(net_output.h_tm.reshape(B * T, -1), net_output.project.weight,
                                                   net_output.project.bias, labels_tm, scale_tm, self.padding_idx,
@@ -54,7 +64,7 @@ class NLLEntropy(_Loss):
             net_output.tok_nll = tok.view(T, B).t()
             return loss
         # a materialised [B,T,V] log-prob tensor: label gather + weighted sum on the HIP kernels (batch-first rows)
-        scale_bf = self._row_scale(labels, B, T).contiguous().view(-1)
+        scale_bf = self._row_scale(labels, B, T, global_count).contiguous().view(-1)
         loss, _tok = ops.NLLGatherFunction.apply(net_output.reshape(B * T, -1), labels.reshape(-1).contiguous(), scale_bf,
                                                  self.padding_idx)
         return loss
@@ -104,13 +114,17 @@ class BatchPriorKL(_Loss):
         self.log_uniform = math.log(1.0 / k)
         self.cat_kl_loss = CatKLLoss()
 
-    def forward(self, log_qy, log_py=None):
-        b_pr, mi, row_kl = ops.LatentLossFunction.apply(log_qy, self.y_size, self.k, parallel.group())
+    def forward(self, log_qy, log_py=None, extra=None):
+        """-> (reg_kl, b_pr, mi), or with `extra` (per-rank sums that ride in the same all-reduce message, e.g. the
+        decoders' non-PAD target counts) -> (reg_kl, b_pr, mi, extra summed over the DP group)."""
+        b_pr, mi, row_kl, stats, extra_g = ops.LatentLossFunction.apply(log_qy, self.y_size, self.k, parallel.group(), extra)
         if not self.use_mutual:
             reg_kl = row_kl
         elif log_py is not None:
-            avg_log_qy = ops.AvgLogQyFunction.apply(log_qy, self.y_size, self.k, parallel.group())
+            avg_log_qy = ops.AvgLogQyFunction.apply(log_qy, self.y_size, self.k, parallel.group(), stats)
             reg_kl = self.cat_kl_loss(avg_log_qy, ops.LogSoftmaxKFunction.apply(log_py), None, unit_average=True)
         else:
             reg_kl = b_pr
+        if extra is not None:
+            return reg_kl, b_pr, mi, extra_g
         return reg_kl, b_pr, mi

@@ -79,6 +79,20 @@ class _SentBase(BaseModel):
         dec_init_state = self.dec_init_connector(sample_y)
         return log_qy, y_ids, dec_init_state
 
+    def _latent_losses(self, log_qy, label_sets, log_py=None):
+        """-> ((reg_kl, b_pr, mi), [global non-PAD count or None per label set]).
+
+        Under data parallelism with 'word' averaging the step needs the global batch statistics of the posterior AND
+        the global non-PAD target count of every decoder; both are known once the encoder has run, so they travel in ONE
+        all-reduce message (y*k+2 sums + one count per decoder) issued here, before the decoders start -- not one
+        collective for the statistics and one per decoder for the counts."""
+        from .. import parallel
+        if parallel.group() is not None and self.nll_loss.avg_type == 'word':
+            local = torch.cat([self.nll_loss.local_count(lab) for lab in label_sets])
+            reg_kl, b_pr, mi, counts = self.bpr_loss(log_qy, log_py, extra=local)
+            return (reg_kl, b_pr, mi), [counts[i:i + 1] for i in range(len(label_sets))]
+        return self.bpr_loss(log_qy, log_py), [None] * len(label_sets)
+
 
 class DiVAE(_SentBase):
     def __init__(self, corpus, config):
@@ -103,13 +117,17 @@ class DiVAE(_SentBase):
 
         labels = out_utts[:, 1:].contiguous()
         dec_inputs = out_utts[:, 0:-1]
+        if mode != GEN:
+            # the latent losses have no random draw and no consumer on the decoder side: computing them first lets their
+            # batch statistics and the decoder's target count share one exchange under data parallelism
+            (reg_kl, b_pr, mi), (count,) = self._latent_losses(
+                log_qy, [labels], self.log_py if getattr(self.config, 'train_prior', False) else None)
         dec_outs, dec_last, dec_ctx = self.decoder(batch_size, dec_inputs, dec_init_state, mode=mode,
                                                    gen_type=gen_type, beam_size=self.beam_size)
         if mode == GEN:
             return dec_ctx, labels
-        nll = self.nll_loss(dec_outs, labels)
+        nll = self.nll_loss(dec_outs, labels, global_count=count)
         self._last_dec_outs = dec_outs
-        reg_kl, b_pr, mi = self.bpr_loss(log_qy, self.log_py if getattr(self.config, 'train_prior', False) else None)
         results = Pack(nll=nll, reg_kl=reg_kl, mi=mi, bpr=b_pr)
         if return_latent:
             results['log_qy'] = log_qy
@@ -211,6 +229,9 @@ class DiVST(_SentBase):
 
         prev_labels = prev_utts[:, 1:].contiguous()
         next_labels = next_utts[:, 1:].contiguous()
+        prev_count = next_count = None
+        if mode != GEN:                                  # one exchange for the statistics and both target counts
+            (reg_kl, b_pr, mi), (prev_count, next_count) = self._latent_losses(log_qy, [prev_labels, next_labels])
         if mode != GEN and self.two_streams and dec_init_state.is_cuda:
             # The two decoders are independent given dec_init_state: the next-utterance branch (decoder + its fused
             # projection / NLL) runs on a side HIP stream beside the previous-utterance branch.  At the script batch
@@ -223,15 +244,15 @@ class DiVST(_SentBase):
             side.wait_stream(cur)
             with ops.concurrent_streams(2):          # each decoder's persistent recurrence may count on half the CUs
                 with torch.cuda.stream(side):
-                    for t in (dec_init_state, next_utts, next_labels):
+                    for t in (dec_init_state, next_utts, next_labels) + ((next_count,) if next_count is not None else ()):
                         t.record_stream(side)
                     next_dec_outs, _, next_dec_ctx = self.next_decoder(batch_size, next_utts[:, 0:-1], dec_init_state,
                                                                        mode=mode, gen_type=gen_type, beam_size=self.beam_size)
-                    next_nll = self.nll_loss(next_dec_outs, next_labels)
+                    next_nll = self.nll_loss(next_dec_outs, next_labels, global_count=next_count)
                     next_nll.record_stream(cur)
                 prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
                                                                    gen_type=gen_type, beam_size=self.beam_size)
-                prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
+                prev_nll = self.nll_loss(prev_dec_outs, prev_labels, global_count=prev_count)
             cur.wait_stream(side)
         else:
             prev_dec_outs, _, prev_dec_ctx = self.prev_decoder(batch_size, prev_utts[:, 0:-1], dec_init_state, mode=mode,
@@ -240,9 +261,8 @@ class DiVST(_SentBase):
                                                                gen_type=gen_type, beam_size=self.beam_size)
             if mode == GEN:
                 return (prev_dec_ctx, next_dec_ctx), (prev_labels, next_labels)
-            prev_nll = self.nll_loss(prev_dec_outs, prev_labels)
-            next_nll = self.nll_loss(next_dec_outs, next_labels)
-        reg_kl, b_pr, mi = self.bpr_loss(log_qy)
+            prev_nll = self.nll_loss(prev_dec_outs, prev_labels, global_count=prev_count)
+            next_nll = self.nll_loss(next_dec_outs, next_labels, global_count=next_count)
         results = Pack(prev_nll=prev_nll, next_nll=next_nll, reg_kl=reg_kl, mi=mi, b_pr=b_pr)
         if return_latent:
             results['log_qy'] = log_qy

@@ -489,22 +489,32 @@ class GumbelLatentFunction(torch.autograd.Function):
 
 
 class LatentLossFunction(torch.autograd.Function):
-    """log_qy[B*y,k] -> (bpr, mi, row_kl) 0-dim tensors; batch statistics are all-reduced over `group`."""
+    """log_qy[B*y,k] -> (bpr, mi, row_kl) 0-dim tensors (+ the reduced statistics and the reduced `extra`).
+
+    Batch statistics are all-reduced over `group` in ONE message: the y*k+2 latent sums and, behind them, whatever
+    per-rank sums the caller hands in as `extra` (a 1-D float tensor: the non-PAD target counts of the step's
+    decoders, whose global values the 'word' NLL divides by -- SURVEY.md 8e "fold into the same message").  Outputs 4
+    and 5 are the reduced statistics [y*k+2] and the reduced extra (None without one); neither carries a gradient."""
 
     @staticmethod
-    def forward(ctx, log_qy, y_size, k, group):
+    def forward(ctx, log_qy, y_size, k, group, extra=None):
         log_qy = _f32c(log_qy)
         dev = log_qy.device
         B = log_qy.shape[0] // y_size
+        n = y_size * k + 2
         nblk = int(lib.laed_latent_stats_blocks())
-        ws = workspace("latent", nblk * (y_size * k + 2), dev)
-        stats = torch.empty(y_size * k + 2, device=dev, dtype=torch.float32)
+        ws = workspace("latent", nblk * n, dev)
+        ne = 0 if extra is None else int(extra.numel())
+        msg = torch.empty(n + ne, device=dev, dtype=torch.float32)
+        stats = msg[:n]
         check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
+        if ne:
+            msg[n:].copy_(extra.reshape(-1))
         Bg = float(B)
         if group is not None:
             import torch.distributed as dist
             from . import parallel
-            parallel.all_reduce_(stats, group)
+            parallel.all_reduce_(msg, group)
             Bg = float(B * dist.get_world_size(group))       # equal shards per rank
         scal = torch.empty(4, device=dev, dtype=torch.float32)
         coef = torch.empty(y_size * k, device=dev, dtype=torch.float32)
@@ -512,10 +522,12 @@ class LatentLossFunction(torch.autograd.Function):
         ctx.save_for_backward(log_qy, coef, stats)
         ctx.meta = (B, Bg, y_size, k)
         ctx.set_materialize_grads(False)          # unused outputs (mi, row-KL in the default model) arrive as None
-        return scal[0], scal[1], scal[2]
+        extra_out = msg[n:] if ne else None
+        ctx.mark_non_differentiable(stats, *([extra_out] if ne else []))
+        return scal[0], scal[1], scal[2], stats, extra_out
 
     @staticmethod
-    def backward(ctx, d_bpr, d_mi, d_rowkl):
+    def backward(ctx, d_bpr, d_mi, d_rowkl, _dstats=None, _dextra=None):
         # mi is only logged by the reference's models (sent_models.py:155-158), but it is an ordinary differentiable
         # member of the returned Pack there, so its gradient is provided too
         log_qy, coef, stats = ctx.saved_tensors
@@ -534,29 +546,32 @@ class LatentLossFunction(torch.autograd.Function):
                 check(lib.laed_latent_mi_coef(ptr(stats), Bg, y_size, k, ptr(c), stream()), "laed_latent_mi_coef")
             check(lib.laed_latent_bwd(ptr(log_qy), ptr(c), ptr(g), mode, B, Bg, y_size, k, ptr(dlq), int(not first),
                                       stream()), "laed_latent_bwd")
-        return dlq, None, None, None
+        return dlq, None, None, None, None
 
 
 class AvgLogQyFunction(torch.autograd.Function):
-    """log_qy[B*y,k] -> avg_log_qy[y,k] = log(mean_b exp(log_qy) + 1e-15) (sent_models.py:138-139); the batch sum is
-    all-reduced over `group`, so every rank holds the global-batch value."""
+    """log_qy[B*y,k] -> avg_log_qy[y,k] = log(mean_b exp(log_qy) + 1e-15) (sent_models.py:138-139).  `stats` = the
+    ALREADY all-reduced batch sums LatentLossFunction returned for the same log_qy (so every rank holds the
+    global-batch value without a second exchange); None: computed and reduced over `group` here."""
 
     @staticmethod
-    def forward(ctx, log_qy, y_size, k, group):
+    def forward(ctx, log_qy, y_size, k, group, stats=None):
         log_qy = _f32c(log_qy)
         dev = log_qy.device
         B = log_qy.shape[0] // y_size
         n = y_size * k
-        nblk = int(lib.laed_latent_stats_blocks())
-        ws = workspace("latent", nblk * (n + 2), dev)
-        stats = torch.empty(n + 2, device=dev, dtype=torch.float32)
-        check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
         Bg = float(B)
         if group is not None:
             import torch.distributed as dist
-            from . import parallel
-            parallel.all_reduce_(stats, group)
             Bg = float(B * dist.get_world_size(group))
+        if stats is None:
+            nblk = int(lib.laed_latent_stats_blocks())
+            ws = workspace("latent", nblk * (n + 2), dev)
+            stats = torch.empty(n + 2, device=dev, dtype=torch.float32)
+            check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
+            if group is not None:
+                from . import parallel
+                parallel.all_reduce_(stats, group)
         avg = torch.empty((y_size, k), device=dev, dtype=torch.float32)
         check(lib.laed_avg_log_fwd(ptr(stats), Bg, n, ptr(avg), stream()), "laed_avg_log_fwd")
         ctx.save_for_backward(log_qy, stats)
@@ -572,7 +587,7 @@ class AvgLogQyFunction(torch.autograd.Function):
         dlq = torch.empty_like(log_qy)
         check(lib.laed_latent_bwd(ptr(log_qy), ptr(coef), None, 1, B, Bg, y_size, k, ptr(dlq), 0, stream()),
               "laed_latent_bwd")
-        return dlq, None, None, None
+        return dlq, None, None, None, None
 
 
 class CatRowsFunction(torch.autograd.Function):

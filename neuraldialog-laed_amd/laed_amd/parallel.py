@@ -32,6 +32,7 @@ def shutdown():
     global _GROUP, _ENABLED
     _GROUP, _ENABLED = None, False
     _GLOO.clear()
+    COLLECTIVES["forward"] = COLLECTIVES["grad"] = 0
 
 
 def group():
@@ -48,6 +49,9 @@ def rank():
 
 
 _GLOO = {}
+# collectives issued since init(): "forward" = loss-statistics exchanges (ops.LatentLossFunction and friends, NLLEntropy),
+# "grad" = the GradReducer's.  Tests assert one forward exchange per DI-VAE / DI-VST step.
+COLLECTIVES = {"forward": 0, "grad": 0}
 
 
 def _is_gloo(group):
@@ -56,7 +60,7 @@ def _is_gloo(group):
     return _GLOO[group]
 
 
-def all_reduce_(t, group=None):
+def all_reduce_(t, group=None, kind="forward"):
     """In-place SUM all-reduce of `t` over `group` (default: the DP group) on the current stream.
 
     Backend "nccl" (RCCL) is stream-ordered and needs nothing else.  Backend "gloo" is only the transport of the tests
@@ -67,6 +71,7 @@ def all_reduce_(t, group=None):
     group = _GROUP if group is None else group
     if t.is_cuda and _is_gloo(group):
         torch.cuda.current_stream(t.device).synchronize()
+    COLLECTIVES[kind] += 1
     dist.all_reduce(t, group=group)
     return t
 
@@ -136,9 +141,9 @@ class GradReducer(object):
                     self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 t.record_stream(self.stream)
-                all_reduce_(t)
+                all_reduce_(t, kind="grad")
         else:                                   # CPU / gloo test path
-            all_reduce_(t)
+            all_reduce_(t, kind="grad")
 
     def _flush(self):
         if not self._pending:
@@ -170,7 +175,7 @@ class GradReducer(object):
                 views.append((p, v))
                 off += k
             self.collectives += 1
-            all_reduce_(flat)
+            all_reduce_(flat, kind="grad")
         if side:
             flat.record_stream(torch.cuda.current_stream())
         for p, v in views:

@@ -10,7 +10,7 @@ inputs + expected outputs are committed.  Both training phases are recorded:
   phase B (kl_w = 1, greedy_q): argmax one-hot from the recognition net, fresh optimizer over the unfrozen params
           (main.py:106-110)
 
-usage:  python tests/golden/make_goldens_dialog.py
+usage:  python tests/golden/make_goldens_dialog.py [aeed_tiny|sted_tiny|aeed_mid|sted_mid ...]
 """
 import os
 from argparse import Namespace
@@ -186,9 +186,19 @@ def run_dialog_model(kind, name, seed, V, B, C, T, cfg_kw):
           {k_: float(G['A/' + k_]) for k_ in keys if 'A/' + k_ in G})
 
 
+JOBS = {
+    'aeed_tiny': lambda: run_dialog_model('aeed', 'aeed_tiny', 21, V=50, B=5, C=4, T=8, cfg_kw={}),
+    'sted_tiny': lambda: run_dialog_model('sted', 'sted_tiny', 22, V=50, B=5, C=3, T=8, cfg_kw=dict(utt_type='rnn')),
+    'aeed_mid': lambda: run_dialog_model('aeed', 'aeed_mid', 23, V=300, B=8, C=5, T=12,
+                                         cfg_kw=dict(embed_size=32, utt_cell_size=24, ctx_cell_size=64, dec_cell_size=64,
+                                                     y_size=4, k=6, max_dec_len=12)),
+    # config 4 (stanford-skip.py: utt_type='rnn', two skip-thought decoders) at the mid shape
+    'sted_mid': lambda: run_dialog_model('sted', 'sted_mid', 24, V=300, B=8, C=5, T=12,
+                                         cfg_kw=dict(utt_type='rnn', embed_size=32, utt_cell_size=24, ctx_cell_size=64,
+                                                     dec_cell_size=64, y_size=4, k=6, max_dec_len=12)),
+}
+
 if __name__ == '__main__':
-    run_dialog_model('aeed', 'aeed_tiny', 21, V=50, B=5, C=4, T=8, cfg_kw={})
-    run_dialog_model('sted', 'sted_tiny', 22, V=50, B=5, C=3, T=8, cfg_kw=dict(utt_type='rnn'))
-    run_dialog_model('aeed', 'aeed_mid', 23, V=300, B=8, C=5, T=12,
-                     cfg_kw=dict(embed_size=32, utt_cell_size=24, ctx_cell_size=64, dec_cell_size=64, y_size=4, k=6,
-                                 max_dec_len=12))
+    import sys
+    for job in (sys.argv[1:] or list(JOBS)):        # no argument: all of them
+        JOBS[job]()

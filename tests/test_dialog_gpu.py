@@ -80,7 +80,7 @@ def check_params(G, tag, model, atol):
         assert d < atol, (tag, n, d)
 
 
-@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny", "aeed_mid"])
+@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny", "aeed_mid", "sted_mid"])
 def test_dialog_model_two_phase_training_vs_reference(name):
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     G = load_golden(name)
@@ -148,7 +148,7 @@ def test_dialog_model_two_phase_training_vs_reference(name):
     check_params(G, "B_p3/", model, 2e-4)
 
 
-@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny", "aeed_mid"])
+@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny", "aeed_mid", "sted_mid"])
 def test_dialog_model_eval_and_greedy_vs_reference(name):
     from laed_amd.enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
     G = load_golden(name)

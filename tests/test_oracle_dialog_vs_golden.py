@@ -76,7 +76,7 @@ def zero_grad(P):
         p.grad = None
 
 
-@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny", "aeed_mid"])
+@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny", "aeed_mid", "sted_mid"])
 def test_dialog_model_phases(name):
     G = load_golden(name)
     kind = str(G["meta/kind"])

@@ -75,7 +75,16 @@ def _worker(rank, world, result_dir):
     # oracle's per-token NLL of this shard (the criterion's arithmetic itself only exists on the GPU)
     labels = torch.from_numpy(G["in/outputs"][b0:b1, 1:].astype(np.int64))
     crit = criterions.NLLEntropy(0, Namespace(avg_type="word", use_gpu=False))
+    f0 = parallel.COLLECTIVES["forward"]
     scale = crit._row_scale(labels, labels.shape[0], labels.shape[1])
+    assert parallel.COLLECTIVES["forward"] == f0 + 1        # standalone criterion: its own count exchange
+    # the models fold that count into the latent-statistics message instead (one forward collective per step): a count
+    # the caller already reduced is used as it is and costs no collective
+    cnt = crit.local_count(labels)
+    parallel.all_reduce_sum_(cnt)
+    f1 = parallel.COLLECTIVES["forward"]
+    scale2 = crit._row_scale(labels, labels.shape[0], labels.shape[1], global_count=cnt)
+    assert parallel.COLLECTIVES["forward"] == f1 and torch.equal(scale, scale2)
     tok = -res["logp"].gather(2, labels.unsqueeze(2)).squeeze(2) * (labels != 0).float()
     nll_share = (tok * scale).sum().reshape(1)
     dist.all_reduce(nll_share)

@@ -70,7 +70,11 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
     feed = {"outputs": G["in/outputs"][b0:b1], "output_lens": [0] * (b1 - b0)}
     if kind == "divst":                                    # two decoders on two HIP streams under the reducer's hooks
         feed["prevs"], feed["nexts"] = G["in/prevs"][b0:b1], G["in/nexts"][b0:b1]
+    c0 = dict(parallel.COLLECTIVES)
     loss = model(feed, mode=TEACH_FORCE)
+    # ONE forward exchange per step: the y*k+2 posterior statistics and the non-PAD target count of every decoder (two
+    # for DI-VST) travel in the same all-reduce message
+    assert parallel.COLLECTIVES["forward"] - c0["forward"] == 1, (parallel.COLLECTIVES, c0)
     model.backward(0, loss)
     opt.reducer.wait()
     torch.cuda.synchronize()
@@ -99,6 +103,8 @@ def _worker(rank, world, result_dir, kind, backend="gloo"):
         # ranks share the GPU: set_device_sharers(world > 1) sends every recurrence to per-step launches
         assert (f, b) == launches0 or world == 1, (f, b, launches0)
     assert opt.reducer.collectives < sum(1 for p in model.parameters() if p.grad is not None)     # coalesced buckets
+    assert parallel.COLLECTIVES["grad"] - c0["grad"] == opt.reducer.collectives
+    assert parallel.COLLECTIVES["forward"] - c0["forward"] == 1          # backward needed no further statistics exchange
     dist.destroy_process_group()
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
     faulthandler.cancel_dump_traceback_later()
