@@ -455,6 +455,9 @@ def main():
                        **({"context_turns": DIALOG_CTX, "phase": args.phase} if is_dialog else {})},
             "step_tflops": main_res["step_tflops"],
             "final_nll": main_res["final_nll"],
+            # sticky count of timed-out in-kernel waits of the persistent GRU kernels (B <= 64 shapes); non-zero = the
+            # numbers above come from poisoned outputs and are void
+            "gru_persist_timeouts": _ops.gru_persist_timeouts(),
             "roofline": main_res["roofline"],
         }
         if alt_res is not None:

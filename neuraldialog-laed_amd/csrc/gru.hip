@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         cur ^= 1;
     }
 
-    laed_mfma_drain();
+    laed_mfma_drain(acc);
     if (WK > 1) {   // every wave hands the rows it does not own to their owners (fixed summation order: wq ascending)
         float* red = smem;   // all waves are past the last barrier: tiles are dead
         float* d = red + ((wq * WM * WU + wu * WM + wm) * 48) * 64 + lane;

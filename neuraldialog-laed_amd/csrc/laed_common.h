@@ -17,12 +17,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // AccVGPRs the fp32 GEMM gained 2 % over all products and 3.7 % on the dW product (S-fixed step 439.5 -> 431.2 ms, same
 // bits).  The constraint "a" is the only way to ask for that form, hence inline asm; the asm is
 // opaque to the compiler's MFMA hazard recognizer, so every reader of `acc` that is not another such MFMA on the same
-// tile must be preceded by laed_mfma_drain() (XDL write -> VALU / v_accvgpr_read needs 18 wait states after a 16-pass op).
+// tile must be preceded by laed_mfma_drain(acc) (XDL write -> VALU / v_accvgpr_read needs 18 wait states after a 16-pass op).
 __device__ __forceinline__ void laed_mfma_32x32x2(f32x16& acc, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void laed_mfma_drain() {
-    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+// The drain carries a DEPENDENCY on every tile it protects: each tile is an in/out operand ("+a") of the drain's asm
+// statements, so any later read of the tile (v_accvgpr_read, extractelement) uses the value the drain "produced" and
+// cannot be scheduled in front of the s_nops -- a memory clobber or `volatile` alone orders memory operations and other
+// volatile asm, not register-only instructions.  The first statement holds the wait states; the statements for the other
+// tiles are empty and ordered behind it (volatile asm statements keep their program order).
+__device__ __forceinline__ void laed_mfma_drain_first(f32x16& acc) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
+}
+__device__ __forceinline__ void laed_mfma_drain_next(f32x16& acc) {
+    asm volatile("" : "+a"(acc));
+}
+template <int N>
+__device__ __forceinline__ void laed_mfma_drain(f32x16 (&acc)[N]) {
+    laed_mfma_drain_first(acc[0]);
+#pragma unroll
+    for (int i = 1; i < N; ++i) laed_mfma_drain_next(acc[i]);
+}
+template <int M, int N>
+__device__ __forceinline__ void laed_mfma_drain(f32x16 (&acc)[M][N]) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (i == 0 && j == 0) laed_mfma_drain_first(acc[0][0]);
+            else laed_mfma_drain_next(acc[i][j]);
+        }
 }
 
 char* laed_err_buf();   // thread-local, 256 bytes (laed_api.hip)

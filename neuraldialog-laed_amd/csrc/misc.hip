@@ -65,6 +65,8 @@ struct AdamMulti {
     int nt;
 };
 
+// The descriptor is indexed with a block-uniform runtime t: the compiler reads it with scalar loads from the kernarg
+// segment (ISA checked: private_segment_fixed_size 0, no scratch_ instruction), not through a per-thread copy.
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti a, AdamConsts c) {
     int t = 0;
     while (t + 1 < a.nt && (int)blockIdx.x >= a.blk0[t + 1]) ++t;        // block-uniform
@@ -161,6 +163,8 @@ extern "C" int laed_adam_step_multi(int ntensors, float* const* p, const float* 
             a.blk0[k + 1] = a.blk0[k] + grid_for(vec ? a.n4[k] + 1 : n[t]);
         }
         if (a.nt == 0) break;
+        // grid_for() caps each tensor at 2048 blocks, so the grid is at most ADAM_MAXT x 2048; checked, not assumed
+        LAED_CHECK_ARG(a.blk0[a.nt] > 0 && a.blk0[a.nt] <= ADAM_MAXT * 2048, "adam_step_multi: block table out of range");
         hipLaunchKernelGGL(adam_multi_kernel, dim3(a.blk0[a.nt]), dim3(256), 0, (hipStream_t)stream, a, c);
         LAED_LAUNCH_CHECK("adam_step_multi");
     }

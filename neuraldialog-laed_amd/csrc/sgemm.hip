@@ -458,7 +458,7 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         __syncthreads();
         cur ^= 1;
     }
-    laed_mfma_drain();        // the accumulators are read (v_accvgpr_read) from here on
+    laed_mfma_drain(acc);        // the accumulators are read (v_accvgpr_read) from here on
 
     if (EPI == 1) {
         // ---- online-softmax epilogue: per row of the block tile, (max, sum exp) over its BN columns and the label's
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void sgemm_glds_kernel(SgemmArgs p) {
     if (t < nsub) step(t, f0, f1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing re-loads must not outlive the block
 
-    laed_mfma_drain();
+    laed_mfma_drain(acc);
     store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
     if (TA && csum_wave) {
 #pragma unroll
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(576, 2) void sgemm_gldsw_kernel(SgemmArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    laed_mfma_drain();
+    laed_mfma_drain(acc);
     store_acc<BM, BN, WGM, WGN, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lk, split);
     if (TA && csum_wave) {
 #pragma unroll

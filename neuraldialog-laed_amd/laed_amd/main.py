@@ -55,8 +55,10 @@ class _Series(object):
         return self._host
 
     def mean(self, last=None):
+        """fp32 mean, as the reference's np.average / np.mean over its list of fp32 loss scalars (laed/main.py:39,49):
+        the early-stopping comparisons and the printed digits then agree with it exactly."""
         v = self.values()
-        return float(np.mean(v if last is None else v[-last:]))
+        return float(np.asarray(v if last is None else v[-last:], dtype=np.float32).mean())
 
     # list protocol, for callers that index / iterate `manager.losses[key]` as the reference's plain lists
     def __len__(self):
@@ -81,7 +83,7 @@ class LossManager(object):
 
     def add_loss(self, loss):
         for key, val in loss.items():
-            if torch.is_tensor(val) and val.dim() == 0:     # skips None, flags and per-row tensors
+            if torch.is_tensor(val) and val.numel() == 1:   # 0-dim or 1-element terms; skips None, flags, per-row tensors
                 self.losses.setdefault(key, _Series()).push(val)
 
     def add_backward_loss(self, loss):
@@ -96,9 +98,9 @@ class LossManager(object):
             m = series.mean(window)
             cells.append("%s %.3f" % (key, m))
             if 'nll' in key:
-                cells.append("PPL %.3f" % np.exp(m))
+                cells.append("PPL %.3f" % np.exp(np.float32(m)))      # fp32 exp, as the reference prints it
         head = name if not prefix else "%s: %s" % (prefix, name)
-        return " ".join([head] + cells)
+        return head + " " + " ".join(cells)         # an empty record prints "name " (trailing blank), as the reference does
 
 
 class EarlyStopping(object):
@@ -157,6 +159,29 @@ def _save_checkpoint(model, config):
     return path
 
 
+def check_persistent_recurrences(model, where):
+    """Raise if any bounded in-kernel wait of the persistent GRU kernels has timed out on this device.
+
+    A wait that gives up poisons its outputs with NaN so that the grid drains (gru_small.hip); in a training run that
+    reads as a loss that diverged.  The counter is sticky and costs one 4-byte device read, so the engine looks at it
+    where the host synchronises anyway (each pseudo-epoch) and names the real cause: something the CU budget does not
+    know about (another process on the GPU, a whole-device grid on a side stream) kept a persistent grid from becoming
+    co-resident.  Models that do not live on a GPU (the scripted stand-ins of the tests) are skipped."""
+    params = getattr(model, "parameters", None)
+    first = next(iter(params()), None) if callable(params) else None
+    if first is None or not first.is_cuda:
+        return 0
+    from . import ops
+    with torch.cuda.device(first.device):
+        n = ops.gru_persist_timeouts()
+    if n:
+        raise RuntimeError("%s: %d inter-workgroup wait(s) of the persistent GRU kernels timed out on %s -- their outputs "
+                           "were poisoned with NaN. The persistent grids could not become co-resident: is another "
+                           "process using this GPU (ops.set_device_sharers), or a whole-device kernel running on a side "
+                           "stream? LAED_GRU_PERSIST=0 selects per-step launches." % (where, n, first.device))
+    return n
+
+
 def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=None):
     """Train until `max_epoch` pseudo-epochs or the patience rule stops it; returns the best validation loss.
 
@@ -196,6 +221,7 @@ def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=
             # ---- pseudo-epoch boundary
             logger.info("Pseudo-epoch %d done; %s", stopper.epochs_done + 1, seen.pprint("Train"))
             valid_loss = validate(model, valid_feed, config, step_no)
+            check_persistent_recurrences(model, "pseudo-epoch %d" % (stopper.epochs_done + 1))
             if gen is not None:
                 gen(model, test_feed, config, evaluator, num_batch=getattr(config, 'preview_batch_num', 1))
             is_best, extended = stopper.observe(valid_loss)

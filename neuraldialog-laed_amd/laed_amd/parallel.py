@@ -112,6 +112,7 @@ class GradReducer(object):
         self.bucket_bytes = bucket_bytes
         self.big_bytes = big_bytes
         self._pending = []                      # (param, producer event) of small gradients not yet flushed
+        self._flats = []                        # coalesced buffers made since the last wait()
         self._pending_bytes = 0
         self._hooks = []
         self.collectives = 0                    # issued since construction (tests / rehearsal bookkeeping)
@@ -177,7 +178,11 @@ class GradReducer(object):
             self.collectives += 1
             all_reduce_(flat, kind="grad")
         if side:
-            flat.record_stream(torch.cuda.current_stream())
+            # `flat` belongs to the reducer stream's pool; its readers are the optimizer (and whoever reads .grad) on the
+            # stream that calls wait() -- not necessarily the stream this hook fired on (DI-VST's side stream, a branch
+            # stream).  wait() records that consumer stream on every buffer made since the last wait, so the caching
+            # allocator cannot hand the block back to the reducer stream while an Adam launch still reads it.
+            self._flats.append(flat)
         for p, v in views:
             p.grad = v                          # consumers (the optimizer) join the side stream in wait() first
 
@@ -202,7 +207,11 @@ class GradReducer(object):
             return
         self._flush()
         if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.stream)
+            for flat in self._flats:
+                flat.record_stream(cur)
+        self._flats = []
 
 
 class _Null(object):

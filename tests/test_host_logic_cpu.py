@@ -418,3 +418,95 @@ def test_persistent_recurrence_budget_streams_divide_processes_forbid(monkeypatc
         assert ops._cu_budget(0) == 1
     ops.set_device_sharers(1)
     assert ops._cu_budget(0) == 0
+
+
+# ---- the same engine, PINNED against the reference's own train() / validate() / LossManager ---------------------------
+def _drive_engine(spec, tmp_path, shape):
+    """Run laed_amd.main.train on the scripted stand-in of tests/engine_stub.py; -> the same record
+    tests/golden/make_goldens_engine.py took from the reference's train()."""
+    import logging
+    import torch
+    from engine_stub import ScriptedFeed, ScriptedModel, engine_config
+    from laed_amd import main as engine
+    model = ScriptedModel(spec["valid"], spec["train"], spec["flush_at"], shape=shape)
+    cfg = engine_config(tmp_path, **spec["cfg"])
+    saves, patience, lines = [], [], []
+
+    class Cap(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+    real_save, real_observe = torch.save, engine.EarlyStopping.observe
+
+    def fake_save(obj, path):
+        model.events.append("save")
+        saves.append(os.path.relpath(path, str(tmp_path)))
+
+    def observe(self, valid_loss):
+        out = real_observe(self, valid_loss)
+        if out[1]:
+            patience.append(float(self.patience))
+        return out
+    cap, root = Cap(), logging.getLogger()
+    old_level = root.level
+    root.addHandler(cap)
+    root.setLevel(logging.INFO)
+    torch.save, engine.EarlyStopping.observe = fake_save, observe
+    try:
+        best = engine.train(model, ScriptedFeed("Train", spec["train_batches"], model),
+                            ScriptedFeed("Valid", spec["valid_batches"], model), ScriptedFeed("Test", 1, model), cfg, "EVAL",
+                            gen=lambda m, feed, config, evaluator, num_batch=1: m.events.append(
+                                "gen:%s:%s:%s" % (feed.name, evaluator, num_batch)))
+    finally:
+        torch.save, engine.EarlyStopping.observe = real_save, real_observe
+        root.removeHandler(cap)
+        root.setLevel(old_level)
+    return model, best, saves, patience, lines
+
+
+@pytest.mark.parametrize("shape", [(1,), ()])
+def test_engine_reproduces_the_reference_train_loop(tmp_path, shape):
+    """`laed_amd.main.train` against tests/golden/engine.npz, the record of /root/reference/laed/main.py:81-181 driven
+    UNMODIFIED over the same scripted scenarios (tests/golden/make_goldens_engine.py): every call on the model, the
+    optimizer, the feeds (epoch_init with its shuffle flag), the preview generator and torch.save in the same order with
+    the same batch counters; the same checkpoints; the same patience updates; the same best validation loss and stopping
+    point; the same windowed "Train" report lines and validation report lines, character for character."""
+    from engine_stub import scenarios
+    from helpers import load_golden
+    G = load_golden("engine")
+    for name, spec in scenarios().items():
+        model, best, saves, patience, lines = _drive_engine(spec, tmp_path, shape)
+        assert model.events == [str(e) for e in G[name + "/events"]], name
+        assert best == float(G[name + "/best"]), name
+        assert patience == G[name + "/patience"].tolist(), name
+        assert (saves or [""]) == [str(p) for p in G[name + "/save_paths"]], name
+        assert sum(1 for e in model.events if e == "get_optimizer") == int(G[name + "/optimizers"]), name
+        want_train = [str(l) for l in G[name + "/log_train"] if str(l)]
+        assert [l for l in lines if ": Train " in l] == want_train, name
+        got_valid = [l for l in lines if l.startswith("Valid ")]
+        want_valid = [str(l) for l in G[name + "/log_valid"]]
+        assert len(got_valid) == len(want_valid), name
+        for g, w, v in zip(got_valid, want_valid, G[name + "/valid_loss"]):
+            assert g.startswith(w + ";") and abs(float(g.split()[-1]) - float(v)) < 1e-6, (name, g, w)
+
+
+def test_validate_and_lossmanager_reproduce_the_reference():
+    """validate() on its own (call order, eval mode, the mean of model_sel_loss over the batches) and LossManager's
+    report strings / avg_loss against the reference's (tests/golden/engine.npz)."""
+    import torch
+    from engine_stub import ScriptedFeed, ScriptedModel, engine_config
+    from helpers import load_golden
+    from laed_amd import main as engine
+    G = load_golden("engine")
+    model = ScriptedModel([2.0], shape=())
+    got = engine.validate(model, ScriptedFeed("Valid", 3, model), engine_config("."), batch_cnt=7)
+    assert abs(got - float(G["validate/return"])) < 1e-6 and model.training is False
+    assert model.events == [str(e) for e in G["validate/events"]]
+    lm = engine.LossManager()
+    for a, b in ((2.0, 0.5), (4.0, 0.25), (3.0, 0.125)):
+        lm.add_loss({"nll": torch.tensor(a), "flag": True, "absent": None, "reg_kl": torch.tensor([b])})
+        lm.add_backward_loss(torch.tensor(a + b))
+    assert lm.pprint("Train") == str(G["lossmanager/pprint_all"])
+    assert lm.pprint("Train", window=2, prefix="1/2-(0.000)") == str(G["lossmanager/pprint_window2_prefix"])
+    assert abs(lm.avg_loss() - float(G["lossmanager/avg_loss"])) < 1e-6
+    lm.clear()
+    assert lm.pprint("Train") == str(G["lossmanager/pprint_cleared"])
