@@ -84,6 +84,11 @@ struct SgemmArgs {
     const int64_t* labels; //   labels[M]
     float* part;           //   part[tile_n][M][2] = (max, sum exp(x - max)) over the tile's columns of row m
     float* lab_logit;      //   lab_logit[m] = logit[m][labels[m]] (written by the one lane that holds it)
+    // phase lock (sync != nullptr): the blocks that are co-resident on one XCD (64 consecutive blocks of its range) meet
+    // every `sync_every` K tiles, so that they keep walking their shared operand strips together (see phase_lock below)
+    unsigned* sync;        //   one zeroed counter per (XCD, group of 64 blocks)
+    int sync_every;        //   K tiles between meetings (a multiple of 2)
+    int sync_shift;        //   log2 of the blocks per meeting group (6: the XCD's 64 resident blocks, 5: one block per CU)
 };
 
 #ifndef SGEMM_BK16_WAVES
@@ -222,6 +227,15 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
     int nwg = gridDim.x, pid = blockIdx.x;
     int xcd = pid & 7, q = nwg >> 3, r = nwg & 7;
     int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+#ifdef LAED_ENV_HOOKS
+    // phase-lock identity: XCD `xcd` runs the q (+1) blocks of its contiguous wg range in order, 64 at a time (32 CUs x 2)
+    const int pl_local = pid >> 3, pl_nx = q + (xcd < r ? 1 : 0);
+    const int pl_g = 1 << p.sync_shift;
+    unsigned* pl_cnt = p.sync ? p.sync + xcd * ((q + pl_g) >> p.sync_shift) + (pl_local >> p.sync_shift) : nullptr;
+    const unsigned pl_size = (unsigned)min(pl_g, pl_nx - (pl_local & ~(pl_g - 1)));
+    unsigned pl_epoch = 0;
+    bool pl_wait = true;
+#endif
     int split = 0;
     if (p.splitk > 1) { split = wg % p.splitk; wg /= p.splitk; }
     const int kbeg = split * p.kper;
@@ -418,9 +432,53 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
             __syncthreads();
 #endif
         };
+#ifdef LAED_ENV_HOOKS
+        // Phase lock (EXPERIMENT, hooks build only, LAED_GEMM_PHASE=<K tiles>; measured and NOT adopted: DESIGN.md section 4
+        // "L2 traffic of the projection's backward products").  The 64 blocks that are resident on an XCD share operand strips through its 4 MB L2 (8 row tiles x 8
+        // column tiles: every strip is read by 8 blocks), which only works while they read the same K range at about
+        // the same time: the L2 holds ~16 K tiles of the group's stream.  Nothing keeps them together -- a block's loads
+        // never stall it (they are issued a whole tile ahead), so a block that falls behind stays behind and re-fetches
+        // what its group already evicted (PMC: 3.2x the fabric traffic the tiling needs on the dW product).  Every
+        // `sync_every` K tiles one thread per block adds itself to the group's counter and waits, BOUNDED, for the
+        // others: lockstep groups also retire together, so the next 64 blocks start together.  A wait that runs out
+        // (the group is not co-resident: odd occupancy, another stream's blocks on the XCD) switches waiting off for
+        // that block -- it keeps counting, so nobody waits for it -- and the product never depends on the counters.
+        auto phase_lock = [&]() {
+            if (tid == 0) {
+                    const unsigned e = ++pl_epoch;
+                    __hip_atomic_fetch_add(pl_cnt + (e & 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pl_wait && e >= 2) {
+                        const unsigned target = pl_size * (((e - 1) >> 2) + 1);
+                        int spins = 0;
+                        while (__hip_atomic_load(pl_cnt + ((e - 1) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                            if (++spins > 64) { pl_wait = false; break; }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                }
+                return;
+            }
+            if (tid == 0) {
+                ++pl_epoch;
+                __hip_atomic_fetch_add(pl_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pl_wait) {
+                    const unsigned target = pl_size * pl_epoch;
+                    int spins = 0;
+                    while (__hip_atomic_load(pl_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (++spins > 64) { pl_wait = false; break; }           // ~30 us
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
+            __syncthreads();
+        };
+#endif
         for (; kt + 2 < nfull; kt += 2) {           // cur == 0 here
             tile_body(std::integral_constant<int, 0>(), kt + 2 + SGEMM_PF2 < nfull);
             tile_body(std::integral_constant<int, 1>(), kt + 3 + SGEMM_PF2 < nfull);
+#ifdef LAED_ENV_HOOKS
+            if (pl_cnt != nullptr && ((kt + 2) % p.sync_every) == 0) phase_lock();
+#endif
         }
         if (kt + 1 < nfull) {
             tile_body(std::integral_constant<int, 0>(), false);
@@ -985,6 +1043,32 @@ int group_m_for(int tiles_m, int tiles_n) {
     return forced > 0 ? forced : 8;
 }
 
+// Phase-lock counters: a ring of slices in a file-scope device array (one slice per launch, zeroed on the launch's stream
+// right before it; a slice comes round again after PL_SLICES further phase-locked launches, and every wait on it is
+// bounded, so a clash between two streams costs time, never correctness).
+constexpr int PL_SLICES = 8, PL_SLICE = 4096;
+__device__ __attribute__((aligned(256))) unsigned g_phase_counters[PL_SLICES * PL_SLICE];
+std::atomic<unsigned> g_phase_next{0};
+
+int phase_every() {      // K tiles between meetings; 0 = off.  LAED_GEMM_PHASE (hooks build) overrides the default
+    static const int v = []() { const char* e = laed_exp_hook("LAED_GEMM_PHASE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+unsigned* phase_slice(hipStream_t stream) {
+    static unsigned* base[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (base[dev] == nullptr) {
+        unsigned* ptr = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g_phase_counters)) != hipSuccess) return nullptr;
+        base[dev] = ptr;
+    }
+    unsigned* sl = base[dev] + (size_t)(g_phase_next.fetch_add(1) % PL_SLICES) * PL_SLICE;
+    if (hipMemsetAsync(sl, 0, PL_SLICE * sizeof(unsigned), stream) != hipSuccess) return nullptr;
+    return sl;
+}
+
 template <int BM, int BN, bool TA, bool TB, bool VEC, int NT = 256, int EPI = 0, int BKT = BK, int PF = 1>
 int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     constexpr int SA = BM + (!TA ? 1 : 4), SB = BN + (TB ? 1 : 4);
@@ -1005,6 +1089,17 @@ int launch_cfg(const SgemmArgs& a, hipStream_t stream) {
     p.group_m = group_m_for(p.tiles_m, p.tiles_n);
     int64_t grid = (int64_t)p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
     if (grid <= 0 || grid > 0x7fffffff) return laed_fail(LAED_E_SIZE, "sgemm: grid %lld out of range", (long long)grid);
+    p.sync = nullptr;
+    p.sync_every = 0;
+    p.sync_shift = 6;
+    if (VEC && EPI == 0 && NT == 512 && BM == 128 && BN == 128 && phase_every() >= 2 && p.splitk <= 1 && a.M % BM == 0 &&
+        a.N % BN == 0 && grid >= 1024 && a.K % BKT == 0 && a.K / BKT >= 4 * phase_every() &&
+        ((grid >> 3) + 16) / 16 * 8 <= PL_SLICE) {
+        static const int shift = []() { const char* e = laed_exp_hook("LAED_GEMM_PHASE_GROUP"); return (e && atoi(e) == 32) ? 5 : (e && atoi(e) == 16) ? 4 : 6; }();
+        p.sync_shift = shift;
+        p.sync_every = phase_every() & ~1;
+        p.sync = phase_slice(stream);          // nullptr (a failed query / memset): the launch simply runs unlocked
+    }
     ProfRec r;
     if (g_prof_on.load(std::memory_order_relaxed) && prof_begin(r, 2.0 * a.M * a.N * a.K,
                                                                (TA ? 2 : (TB ? 0 : 1)) * 2 + (BM == 128 ? 0 : 1), stream)) {
@@ -1248,7 +1343,7 @@ static int sgemm_dispatch(bool transA, bool transB, int M, int N, int K,
     a.colsum_acc = colsum_accumulate ? 1 : 0;
     a.tiles_m = a.tiles_n = 0; a.group_m = 8;
     a.splitk = 1; a.kper = 0; a.ws = ws; a.ws_colsum = nullptr;
-    a.labels = nullptr; a.part = nullptr; a.lab_logit = nullptr;
+    a.labels = nullptr; a.part = nullptr; a.lab_logit = nullptr; a.sync = nullptr; a.sync_every = 0; a.sync_shift = 6;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (!transA && transB) return launch_layout<false, true>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
     if (!transA && !transB) return launch_layout<false, false>(a, vec, ws_floats, raw_partials, splits_out, force_split, stream);
@@ -1268,7 +1363,7 @@ int laed_sgemm_softmax_stats_impl(int M, int N, int K, const float* A, int64_t l
     a.accumulate = 0; a.colsum_acc = 0;
     a.tiles_m = a.tiles_n = 0; a.group_m = 8;
     a.splitk = 1; a.kper = ((K + BK - 1) / BK) * BK; a.ws = nullptr; a.ws_colsum = nullptr;
-    a.labels = labels; a.part = part; a.lab_logit = lab_logit;
+    a.labels = labels; a.part = part; a.lab_logit = lab_logit; a.sync = nullptr; a.sync_every = 0; a.sync_shift = 6;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     return vec ? launch_cfg<128, 128, false, true, true, 512, 1, 16>(a, stream)
                : launch_cfg<128, 128, false, true, false, 512, 1>(a, stream);
@@ -1310,7 +1405,7 @@ int laed_sgemm_argmax_impl(int M, int N, int K, const float* A, int64_t lda, con
     a.accumulate = 0; a.colsum_acc = 0;
     a.tiles_m = a.tiles_n = 0; a.group_m = 8;
     a.splitk = 1; a.kper = ((K + BK - 1) / BK) * BK; a.ws = nullptr; a.ws_colsum = nullptr;
-    a.labels = nullptr; a.part = part; a.lab_logit = nullptr;
+    a.labels = nullptr; a.part = part; a.lab_logit = nullptr; a.sync = nullptr; a.sync_every = 0; a.sync_shift = 6;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     LAED_TRY((vec ? launch_cfg<128, 128, false, true, true, 512, 2, 16>(a, stream)
                   : launch_cfg<128, 128, false, true, false, 512, 2>(a, stream)));

@@ -34,24 +34,25 @@ def run(path):
     # the projection's dW product with workspace (tail split allowed)
     lib.laed_sgemm_ws.argtypes = [i, i, i, i, i, p, i, p, i, p, i, p, i, p, i, p, ctypes.c_int64, p]
     lib.laed_sgemm_ws.restype = i
-    M, N, K = 50000, 1024, 8192
-    A = torch.randn((K, M), device="cuda"); B = torch.randn((K, N), device="cuda"); C = torch.zeros((M, N), device="cuda")
-    cs = torch.zeros(M, device="cuda")
-    ws = torch.empty(8 * 8192 * 1024, device="cuda")
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    f = lambda: lib.laed_sgemm_ws(1, 0, M, N, K, A.data_ptr(), M, B.data_ptr(), N, C.data_ptr(), N, None, 1, cs.data_ptr(), 1,
-                                  ws.data_ptr(), ws.numel(), st)
-    for _ in range(2):
-        assert f() == 0
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
-    out.append("TN dW+ws %.3f ms %.1f TF" % (ms, 2.0 * M * N * K / ms / 1e9))
+    for K in (8192, 40960):
+        M, N = 50000, 1024
+        A = torch.randn((K, M), device="cuda"); B = torch.randn((K, N), device="cuda"); C = torch.zeros((M, N), device="cuda")
+        cs = torch.zeros(M, device="cuda")
+        ws = torch.empty(8 * 8192 * 1024, device="cuda")
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        f = lambda: lib.laed_sgemm_ws(1, 0, M, N, K, A.data_ptr(), M, B.data_ptr(), N, C.data_ptr(), N, None, 1, cs.data_ptr(), 1,
+                                      ws.data_ptr(), ws.numel(), st)
+        for _ in range(2):
+            assert f() == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        out.append("TN dW+ws K=%d %.3f ms %.1f TF" % (K, ms, 2.0 * M * N * K / ms / 1e9))
     print(path.split("/")[-1], " | ".join(out), flush=True)
 
 
