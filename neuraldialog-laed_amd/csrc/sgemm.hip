@@ -434,8 +434,8 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         };
 #ifdef LAED_ENV_HOOKS
         // Phase lock (EXPERIMENT, hooks build only, LAED_GEMM_PHASE=<K tiles>; measured and NOT adopted: DESIGN.md section 4
-        // "L2 traffic of the projection's backward products").  The 64 blocks that are resident on an XCD share operand strips through its 4 MB L2 (8 row tiles x 8
-        // column tiles: every strip is read by 8 blocks), which only works while they read the same K range at about
+        // "L2 traffic of the projection's backward products").
+        // The 64 blocks that are resident on an XCD share operand strips through its 4 MB L2 (8 row tiles x 8 column tiles: every strip is read by 8 blocks), which only works while they read the same K range at about
         // the same time: the L2 holds ~16 K tiles of the group's stream.  Nothing keeps them together -- a block's loads
         // never stall it (they are issued a whole tile ahead), so a block that falls behind stays behind and re-fetches
         // what its group already evicted (PMC: 3.2x the fabric traffic the tiling needs on the dW product).  Every
@@ -444,20 +444,6 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
         // (the group is not co-resident: odd occupancy, another stream's blocks on the XCD) switches waiting off for
         // that block -- it keeps counting, so nobody waits for it -- and the product never depends on the counters.
         auto phase_lock = [&]() {
-            if (tid == 0) {
-                    const unsigned e = ++pl_epoch;
-                    __hip_atomic_fetch_add(pl_cnt + (e & 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (pl_wait && e >= 2) {
-                        const unsigned target = pl_size * (((e - 1) >> 2) + 1);
-                        int spins = 0;
-                        while (__hip_atomic_load(pl_cnt + ((e - 1) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                            if (++spins > 64) { pl_wait = false; break; }
-                            __builtin_amdgcn_s_sleep(8);
-                        }
-                    }
-                }
-                return;
-            }
             if (tid == 0) {
                 ++pl_epoch;
                 __hip_atomic_fetch_add(pl_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
