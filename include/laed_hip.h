@@ -75,6 +75,15 @@ int laed_embed_gather(const int64_t* ids, int64_t rows, const float* table, int 
 /* scatter-add with `ws` (laed_embed_scatter_workspace bytes, 256-byte aligned; not needed for rows <= 4096) is
  * DETERMINISTIC: stable sort of (id, position) + fixed-order segment sums, no float atomics.  ws == NULL for more
  * than 4096 rows falls back to fp32 atomics (order-dependent rounding). */
+/* Batch-first ids in, time-major everything out, one launch: out_tm row t*B + b = table[ids[b*ld_ids + t]] (the
+ * transposing copy of the ids that Embedding.forward made before the gather, sent_models.py:99 / decoders.py:155, is
+ * folded in); ids_tm (may be NULL) receives the transposed ids the backward scatter-add walks.  Input dropout
+ * (decoders.py:156): keep_in = an injected time-major mask [T][B][E], or use_rng != 0 = draw (b, t, c) as number
+ * rng_offset + (b*T + t)*E + c of stream `seed` (the index laed_dropout_keep_mask gives a batch-first mask); either way
+ * keep_out (may be NULL) receives the time-major mask for the backward pass. */
+int laed_embed_gather_bt(const int64_t* ids, int64_t ld_ids, int B, int T, const float* table, int V, int E,
+                         const uint8_t* keep_in, int use_rng, float drop_p, uint64_t seed, uint64_t rng_offset,
+                         float* out_tm, int64_t* ids_tm, uint8_t* keep_out, void* stream);
 int64_t laed_embed_scatter_workspace(int64_t rows, int V, int E);
 int laed_embed_scatter_add(const int64_t* ids, int64_t rows, const float* dout, int V, int E,
                            const uint8_t* keep, float drop_p, int64_t pad_id, float* dtable,
@@ -145,6 +154,10 @@ int laed_gru_persist_launches(unsigned* fwd_host, unsigned* bwd_host);
  * ------------------------------------------------------------------------------------------ */
 int laed_gumbel_latent_fwd(const float* logits, const float* u, int64_t R, int k, float tau, int hard,
                            float* y, int64_t* ids, float* log_qy, void* stream);
+/* the same with the uniforms drawn inside the kernel (draw offset + r*k + c of stream `seed`: bit-identical to
+ * laed_uniform followed by laed_gumbel_latent_fwd; replaces the CPU torch.rand + copy of nn_lib.py:233-235) */
+int laed_gumbel_latent_fwd_rng(const float* logits, int64_t R, int k, float tau, int hard, uint64_t seed, uint64_t offset,
+                               float* y, int64_t* ids, float* log_qy, void* stream);
 int laed_gumbel_latent_bwd(const float* y, const float* dy, const float* log_qy, const float* dlog_qy,
                            int64_t R, int k, float tau, float* dlogits, void* stream);
 
@@ -164,6 +177,10 @@ int laed_gumbel_latent_bwd(const float* y, const float* dy, const float* log_qy,
 int laed_latent_stats_blocks(void);
 int laed_latent_stats(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats, void* stream);
 int laed_latent_finalize(const float* stats, double B_global, int y, int k, float* scal, float* coef, void* stream);
+/* laed_latent_stats + laed_latent_finalize without an exchange between them (one GPU: B_global = B), two launches
+ * instead of three, same bits */
+int laed_latent_stats_finalize(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats,
+                               float* scal, float* coef, void* stream);
 /* Allocation-free variant of laed_latent_stats.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
  * allocate or bring a workspace -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
  * Same outputs as laed_latent_stats (bit for bit: same kernels, same fixed-order reduction); the block partials live
@@ -292,6 +309,14 @@ int laed_proj_argmax(const float* h, const float* proj_w, const float* proj_b, i
 /* masked reductions used by NLLEntropy's averaging modes (criterions.py:47-68):
  * out[0] = sum_r tok_nll[r], out[1] = #(labels != pad). */
 int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int64_t N, int64_t pad_id, float* out, void* stream);
+/* What NLLEntropy.forward derives from the labels (criterions.py:43-72), one single-block launch: the per-row loss weights
+ * of the averaging mode (avg_mode 0 = None: 1; 1 = 'seq': 1/denom; 2 = 'real_word': 1 / (sign(labels).sum(row) * denom);
+ * 3 = 'word': 1 / count, count = global_count[0] if given (already all-reduced) else this batch's own non-PAD count;
+ * denom = B * world size), the labels re-ordered for the consumer (labels[b*ld + t] -> time-major t*B + b, or batch-first;
+ * labels_out may be NULL) and, if local_count != NULL, this batch's non-PAD count. */
+int laed_nll_prepare(const int64_t* labels, int64_t ld, int B, int T, int64_t pad_id, int avg_mode, double denom,
+                     const float* global_count, int time_major, int64_t* labels_out, float* scale_out,
+                     float* local_count, void* stream);
 
 /* NLLEntropy on a dense log-prob tensor (criterions.py:43-72 handed a materialised [N,V] input instead of the lazy
  * decoder handle): tok_nll[r] = labels[r] == pad_id ? 0 : -logp[r][labels[r]]  (row stride ld >= V);
@@ -350,6 +375,7 @@ int laed_rmsprop_step(float* p, const float* g, float* square_avg, float* moment
 int laed_dot(const float* a, const float* b, int64_t n, float* out, void* stream);      /* out[0] = sum a*b (one block, fixed order) */
 int laed_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream);   /* y = a*x + b*y */
 int laed_scale_by_dev(float* y, const float* x, const float* s, int64_t n, void* stream); /* y = s[0]*x */
+int laed_scale_by_dev_multi(int ntensors, float* const* y, const int64_t* n, const float* s, void* stream); /* y_t *= s[0], <= 8 tensors, one launch */
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): when enabled, every GEMM launch is bracketed by HIP events

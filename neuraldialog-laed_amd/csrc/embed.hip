@@ -212,6 +212,48 @@ __global__ __launch_bounds__(256) void uniform_kernel(float* __restrict__ u, int
         u[i] = uniform01(seed, offset + (uint64_t)i);
 }
 
+// Batch-first ids in, time-major everything out, in one pass: out row r = t*B + b takes table[ids[b*ld + t]]; the
+// transposed ids (what the backward scatter-add walks) and -- with dropout -- the keep mask are written as by-products.
+// Dropout decisions come from an injected time-major mask (keep_in) or from the counter RNG: element (b, t, c) is draw
+// rng_offset + (b*T + t)*E + c of stream `seed`, the index laed_dropout_keep_mask gives a batch-first [B,T,E] mask.
+template <bool VEC>
+__global__ __launch_bounds__(256) void embed_gather_bt_kernel(const int64_t* __restrict__ ids, int64_t ld, int B, int T,
+                                                              const float* __restrict__ table, int V, int E,
+                                                              const uint8_t* __restrict__ keep_in, int use_rng, float p,
+                                                              uint64_t seed, uint64_t rng_offset, float scale,
+                                                              float* __restrict__ out, int64_t* __restrict__ ids_tm,
+                                                              uint8_t* __restrict__ keep_out) {
+    constexpr int VW = VEC ? 4 : 1;
+    const int epr = E / VW;
+    const int64_t n = (int64_t)B * T * epr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / epr;                     // time-major row t*B + b
+        const int c = (int)(i - r * epr) * VW;
+        const int t = (int)(r / B), b = (int)(r - (int64_t)t * B);
+        int64_t id = ids[(int64_t)b * ld + t];
+        if (c == 0 && ids_tm != nullptr) ids_tm[r] = id;
+        if (id < 0 || id >= V) id = 0;
+        float v[VW];
+        if (VEC) {
+            const float4 q = *reinterpret_cast<const float4*>(table + id * E + c);
+            v[0] = q.x; v[1 % VW] = q.y; v[2 % VW] = q.z; v[3 % VW] = q.w;
+        } else {
+            v[0] = table[id * E + c];
+        }
+        if (keep_in != nullptr || use_rng) {
+            const uint64_t e0 = rng_offset + ((uint64_t)b * T + t) * E + c;
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                const uint8_t kk = keep_in != nullptr ? keep_in[r * E + c + j] : (uniform01(seed, e0 + j) >= p ? 1 : 0);
+                if (keep_out != nullptr) keep_out[r * E + c + j] = kk;
+                v[j] = kk ? v[j] * scale : 0.f;
+            }
+        }
+        if (VEC) *reinterpret_cast<float4*>(out + r * E + c) = make_float4(v[0], v[1 % VW], v[2 % VW], v[3 % VW]);
+        else out[r * E + c] = v[0];
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t b = cdiv64(n, 256);
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -232,6 +274,25 @@ extern "C" int laed_embed_gather(const int64_t* ids, int64_t rows, const float* 
     else hipLaunchKernelGGL((embed_gather_kernel<false>), dim3(grid_for(rows * E)), dim3(256), 0, (hipStream_t)stream,
                             ids, rows, table, V, E, keep, scale, out);
     LAED_LAUNCH_CHECK("embed_gather");
+    return 0;
+}
+
+extern "C" int laed_embed_gather_bt(const int64_t* ids, int64_t ld_ids, int B, int T, const float* table, int V, int E,
+                                    const uint8_t* keep_in, int use_rng, float drop_p, uint64_t seed, uint64_t rng_offset,
+                                    float* out_tm, int64_t* ids_tm, uint8_t* keep_out, void* stream) {
+    LAED_CHECK_ARG(B >= 0 && T >= 0 && V > 0 && E > 0 && ld_ids >= T, "embed_gather_bt: bad size");
+    LAED_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "embed_gather_bt: dropout p must be in [0,1)");
+    if (B == 0 || T == 0) return 0;
+    LAED_CHECK_ARG(ids && table && out_tm, "embed_gather_bt: null pointer");
+    LAED_CHECK_ARG(!(use_rng && keep_in), "embed_gather_bt: an injected mask and the RNG exclude each other");
+    const float scale = 1.0f / (1.0f - drop_p);
+    const int64_t rows = (int64_t)B * T;
+    const bool vec = (E % 4 == 0) && aligned16(table) && aligned16(out_tm);
+    if (vec) hipLaunchKernelGGL((embed_gather_bt_kernel<true>), dim3(grid_for(rows * (E / 4))), dim3(256), 0, (hipStream_t)stream,
+                                ids, ld_ids, B, T, table, V, E, keep_in, use_rng, drop_p, seed, rng_offset, scale, out_tm, ids_tm, keep_out);
+    else hipLaunchKernelGGL((embed_gather_bt_kernel<false>), dim3(grid_for(rows * E)), dim3(256), 0, (hipStream_t)stream,
+                            ids, ld_ids, B, T, table, V, E, keep_in, use_rng, drop_p, seed, rng_offset, scale, out_tm, ids_tm, keep_out);
+    LAED_LAUNCH_CHECK("embed_gather_bt");
     return 0;
 }
 

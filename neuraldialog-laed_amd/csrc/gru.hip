@@ -423,7 +423,10 @@ extern "C" int laed_gru_fwd_cus(const float* x, const float* w_ih, const float* 
     LAED_CHECK_ARG(x && w_ih && w_hh && b_ih && b_hh && hbuf && gates, "gru_fwd: null pointer");
     const int64_t BH = (int64_t)B * H;
     LAED_CHECK_ARG((int64_t)T * B < 0x7fffffff, "gru_fwd: T*B too large");
-    if (h0 != nullptr) {
+    // small batches: packed-operand step kernels (gru_small.hip); their preparation launch also writes hbuf[0]
+    const bool small = ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_fwd_ws(B, H);
+    if (small) {
+    } else if (h0 != nullptr) {
         if (h0 != hbuf) {
             hipError_t e = hipMemcpyAsync(hbuf, h0, BH * sizeof(float), hipMemcpyDeviceToDevice, stream);
             if (e != hipSuccess) return laed_fail((int)e, "gru_fwd: h0 copy failed");
@@ -434,9 +437,7 @@ extern "C" int laed_gru_fwd_cus(const float* x, const float* w_ih, const float* 
     }
     // hoisted input projection for every timestep: gates[T*B][3H] = x[T*B][E] W_ih^T + b_ih
     LAED_TRY(laed_sgemm_impl(false, true, T * B, 3 * H, E, x, E, w_ih, E, gates, 3 * H, b_ih, false, nullptr, false, stream));
-    // small batches: packed-operand step kernels (gru_small.hip)
-    if (ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_fwd_ws(B, H))
-        return laed_gru_small_fwd(w_hh, b_hh, hbuf, gates, hn, T, B, H, ws, cu_budget, stream);
+    if (small) return laed_gru_small_fwd(w_hh, b_hh, h0, hbuf, gates, hn, T, B, H, ws, cu_budget, stream);
     for (int t = 0; t < T; ++t) {
         GruStepArgs a;
         a.hprev = hbuf + (int64_t)t * BH;
@@ -472,10 +473,6 @@ extern "C" int laed_gru_bwd_cus(const float* x, const float* w_ih, const float* 
                    "gru_bwd: null pointer");
     LAED_CHECK_ARG((int64_t)T * B < 0x7fffffff, "gru_bwd: T*B too large");
     const int64_t BH = (int64_t)B * H;
-    hipError_t e;
-    if (dhT != nullptr) e = hipMemcpyAsync(dh0, dhT, BH * sizeof(float), hipMemcpyDeviceToDevice, stream);
-    else e = hipMemsetAsync(dh0, 0, BH * sizeof(float), stream);
-    if (e != hipSuccess) return laed_fail((int)e, "gru_bwd: dh init failed");
     const int nblk = (int)((BH + 255) / 256 < 2048 ? (BH + 255) / 256 : 2048);
     if (ws == nullptr) ws_floats = 0;
     // split-bf16 mode: bring the big products to the K-contiguous (x W^T) form with transposed fp32 copies carved
@@ -495,7 +492,14 @@ extern "C" int laed_gru_bwd_cus(const float* x, const float* w_ih, const float* 
     int nparts = 0;
     // small batches: one fused launch per step (gru_small.hip) over a packed copy of W_hh^T at the front of ws
     const bool small = ws != nullptr && aligned16(ws) && laed_gru_small_ok(B, H) && ws_floats >= laed_gru_small_bwd_ws(B, H);
-    if (small) LAED_TRY(laed_gru_small_bwd(w_hh, hbuf, hn, dout, gates, dgh, dh0, T, B, H, ws, cu_budget, stream));
+    if (small) {      // its preparation launch also sets dh0 = dhT (or zeros)
+        LAED_TRY(laed_gru_small_bwd(w_hh, hbuf, hn, dout, dhT, gates, dgh, dh0, T, B, H, ws, cu_budget, stream));
+    } else {
+        hipError_t e;
+        if (dhT != nullptr) e = hipMemcpyAsync(dh0, dhT, BH * sizeof(float), hipMemcpyDeviceToDevice, stream);
+        else e = hipMemsetAsync(dh0, 0, BH * sizeof(float), stream);
+        if (e != hipSuccess) return laed_fail((int)e, "gru_bwd: dh init failed");
+    }
     for (int t = small ? -1 : T - 1; t >= 0; --t) {
         GruBwdStepArgs a;
         a.parts = ws;

@@ -501,7 +501,30 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
 }
 
 // wp[wg][q][c][e] = W_hh[(c / UF) H + wg UF + c % UF][4q + e]      (one float4 per thread)
-__global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wp) {
+// The same launch also prepares the recurrence's start (all of it independent of the packing): hbuf0 = h0 (zeros for
+// h0 == nullptr) with its quad-major image xq[grp][q][row][e] (rows_to_quads_kernel's layout, padded rows zero), and
+// the persistent kernel's arrival counters cleared -- one launch instead of memset/copy + pack + rows_to_quads + memset.
+__global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wp,
+                                                         const float* __restrict__ h0, float* __restrict__ hbuf0, int B, int BP,
+                                                         int groups, float* __restrict__ xq, unsigned* __restrict__ sync) {
+    if (xq != nullptr) {
+        const int64_t per = (int64_t)(H / 4) * BP, nq = per * groups;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+            const int grp = (int)(i / per);
+            const int64_t r = i - (int64_t)grp * per;
+            const int row = grp * BP + (int)(r % BP);
+            const int q = (int)(r / BP);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < B) {
+                if (h0 != nullptr) { const float* s = h0 + (int64_t)row * H + 4 * q; v = make_float4(s[0], s[1], s[2], s[3]); }
+                float* hb = hbuf0 + (int64_t)row * H + 4 * q;
+                hb[0] = v.x; hb[1] = v.y; hb[2] = v.z; hb[3] = v.w;
+            }
+            float* d = xq + i * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    if (sync != nullptr && blockIdx.x == 0 && threadIdx.x < 160) sync[threadIdx.x] = 0u;
     constexpr int NC = 3 * UF;
     const int64_t n = (int64_t)(H / UF) * (H / 4) * NC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -515,7 +538,14 @@ __global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict
 }
 
 // wpT[wg][q][c][e] = W_hh[4q + e][wg UB + c],  q < 3H/4
-__global__ __launch_bounds__(256) void pack_w_bwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wpT) {
+// also: dh0 = dhT (zeros for dhT == nullptr) and the persistent kernel's arrival counters cleared
+__global__ __launch_bounds__(256) void pack_w_bwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wpT,
+                                                         const float* __restrict__ dhT, float* __restrict__ dh0, int64_t BH,
+                                                         unsigned* __restrict__ sync) {
+    if (dh0 != nullptr && dh0 != dhT)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < BH; i += (int64_t)gridDim.x * blockDim.x)
+            dh0[i] = dhT != nullptr ? dhT[i] : 0.f;
+    if (sync != nullptr && blockIdx.x == 0 && threadIdx.x < 160) sync[threadIdx.x] = 0u;
     const int64_t n = (int64_t)(H / UB) * (3 * H / 4) * UB;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % UB);
@@ -653,13 +683,12 @@ int64_t laed_gru_small_bwd_ws(int B, int H) {
 }
 
 // forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
-int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
-                       float* ws, int cu_budget, hipStream_t stream) {
+// h0: initial state [B][H] (nullptr = zeros); hbuf[0] is written here (h0 == hbuf is allowed).
+int laed_gru_small_fwd(const float* w_hh, const float* b_hh, const float* h0, float* hbuf, float* gates, float* hn, int T, int B,
+                       int H, float* ws, int cu_budget, hipStream_t stream) {
     int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wp = ws;
-    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wp);
-    LAED_LAUNCH_CHECK("gru_small pack_w_fwd");
     // default: one persistent launch with LDS-resident W_hh (4.9 vs 6.3 us per step + launch gaps at B = 30, H = 512);
     // LAED_GRU_PERSIST=0 selects the per-step launches below
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
@@ -674,12 +703,12 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
         NG = pg.groups;
     }
     float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP * NG};
-    hipLaunchKernelGGL(rows_to_quads_kernel, dim3(32 * NG), dim3(256), 0, stream, (const float*)hbuf, B, H, BP, NG, hx[0]);
-    LAED_LAUNCH_CHECK("gru_small rows_to_quads");
+    // a 128-byte line of arrival counters per group (<= 4) + the flag, cleared by the preparation launch
+    unsigned* sync = persistent ? reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP * NG) : nullptr;
+    // one preparation launch: pack W_hh, hbuf[0] = h0 (or zeros) + its quad-major image, clear the counters
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wp, h0, hbuf, B, BP, NG, hx[0], sync);
+    LAED_LAUNCH_CHECK("gru_small prepare_fwd");
     if (persistent) {
-        unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP * NG);
-        hipError_t e = hipMemsetAsync(sync, 0, 160 * sizeof(float), stream);      // a 128-byte line per group (<= 4) + the flag
-        if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
         PersistFwdArgs a;
         a.hx0 = hx[0]; a.hx1 = hx[1]; a.wp = wp; a.b_hh = b_hh; a.hbuf = hbuf; a.gates = gates; a.hn = hn; a.sync = sync;
         a.T = T; a.B = B; a.H = H; a.nkw = k_waves(H);
@@ -717,13 +746,11 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float*
 
 // backward recurrence over all T steps (gate gradients + dh chain); dh0 holds dh_T on entry and dh_0 on return.
 // ws: laed_gru_small_bwd_ws floats, 16-byte aligned.
-int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, float* gates, float* dgh,
-                       float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream) {
+int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, const float* dhT, float* gates,
+                       float* dgh, float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream) {
     const int BP = laed_gru_small_bp(B), NG = small_groups(B);
     const int64_t BH = (int64_t)B * H;
     float* wpT = ws;
-    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT);
-    LAED_LAUNCH_CHECK("gru_small pack_w_bwd");
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
     const int cu_limit = laed_persist_cu_limit(cu_budget);
     if (persist && NG == 1 && H / UB <= cu_limit) {
@@ -731,14 +758,15 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
         const int PBP = pg.rows, PG = pg.groups;
         float* pdx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * PBP * PG};
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * PBP * PG);
-        hipError_t e = hipMemsetAsync(sync, 0, 160 * sizeof(float), stream);      // a 128-byte line per group (<= 4) + the flag
-        if (e != hipSuccess) return laed_fail((int)e, "gru_small: sync memset failed");
         PersistBwdArgs a;
         a.dx0 = pdx[0]; a.dx1 = pdx[1]; a.wpT = wpT; a.dout = dout; a.hbuf = hbuf; a.hn = hn; a.gates = gates; a.dgh = dgh;
         a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H);
         size_t lds = ((size_t)3 * H * UB + (size_t)NW * PBP * UB) * sizeof(float);
         if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU
         if (lds <= 160 * 1024) {
+            // one preparation launch: pack W_hh^T, dh0 = dhT (or zeros), clear the arrival counters (a line per group + flag)
+            hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT, dhT, dh0, BH, sync);
+            LAED_LAUNCH_CHECK("gru_small prepare_bwd");
             auto go = [&](auto kern) -> int {
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e2 != hipSuccess) return laed_fail((int)e2, "gru_small: hipFuncSetAttribute failed");
@@ -756,6 +784,8 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
             return 0;
         }
     }
+    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wpT, dhT, dh0, BH, (unsigned*)nullptr);
+    LAED_LAUNCH_CHECK("gru_small prepare_bwd");
     float* dx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * BP * NG};
     for (int t = T - 1; t >= -1; --t) {
         SmallBwdArgs a;

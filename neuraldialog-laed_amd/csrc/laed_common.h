@@ -135,10 +135,11 @@ int64_t laed_gru_small_fwd_ws(int B, int H);
 int64_t laed_gru_small_bwd_ws(int B, int H);
 // cu_budget: CUs a persistent (all-workgroups-resident) grid may count on; 0 = the whole device
 int laed_persist_cu_limit(int cu_budget);
-int laed_gru_small_fwd(const float* w_hh, const float* b_hh, float* hbuf, float* gates, float* hn, int T, int B, int H,
-                       float* ws, int cu_budget, hipStream_t stream);
-int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, float* gates, float* dgh,
-                       float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream);
+// h0 / dhT: initial state / incoming gradient of the last state (nullptr = zeros); hbuf[0] / dh0 are initialised inside
+int laed_gru_small_fwd(const float* w_hh, const float* b_hh, const float* h0, float* hbuf, float* gates, float* hn, int T, int B,
+                       int H, float* ws, int cu_budget, hipStream_t stream);
+int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, const float* dhT, float* gates,
+                       float* dgh, float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream);
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -25,7 +25,8 @@ template <int W>
 __global__ __launch_bounds__(256) void gumbel_latent_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
                                                                 int64_t R, int k, float tau, int hard,
                                                                 float* __restrict__ y, int64_t* __restrict__ ids,
-                                                                float* __restrict__ log_qy) {
+                                                                float* __restrict__ log_qy, int use_rng, uint64_t seed,
+                                                                uint64_t rng_offset) {
     constexpr int RPB = 256 / W;
     const int c = threadIdx.x % W;
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / W;
@@ -39,11 +40,14 @@ __global__ __launch_bounds__(256) void gumbel_latent_fwd_kernel(const float* __r
     const float s = grp_sum<W>(e);
     if (valid && log_qy != nullptr) log_qy[off] = (l - m) - logf(s);
 
-    if (u == nullptr) return;   // posterior only ("Hidden2Discrete"); block-uniform: no shuffles follow for anyone
+    if (u == nullptr && !use_rng) return;   // posterior only ("Hidden2Discrete"); block-uniform: no shuffles follow for anyone
     // y = softmax((logits + g)/tau), g = -log(-log(u+eps)+eps)  (nn_lib.py:232-242)
     float a = -INFINITY;
     if (valid) {
-        const float g = -logf(-logf(u[off] + 1e-20f) + 1e-20f);
+        // the uniform is replayed from the caller's buffer or drawn here from the counter RNG: element (row, c) is draw
+        // number rng_offset + row*k + c of stream `seed`, exactly what laed_uniform would have written at u[off]
+        const float uu = use_rng ? uniform01(seed, rng_offset + (uint64_t)off) : u[off];
+        const float g = -logf(-logf(uu + 1e-20f) + 1e-20f);
         a = (l + g) / tau;
     }
     const float m2 = grp_max<W>(a);
@@ -158,10 +162,9 @@ __global__ __launch_bounds__(256) void latent_stats_combine_kernel(const float* 
     }
 }
 
-__global__ __launch_bounds__(256) void latent_finalize_kernel(const float* __restrict__ stats, float Bg, int y, int k,
-                                                              float* __restrict__ scal, float* __restrict__ coef) {
+__device__ __forceinline__ void latent_finalize_block(const float* stats, float Bg, int y, int k, float* __restrict__ scal,
+                                                      float* __restrict__ coef, float* s_kl, float* s_h) {
     // one block; thread e handles class element e of [y][k]; per-y sums through LDS
-    __shared__ float s_kl[MAXE * 256], s_h[MAXE * 256];
     const int yk = y * k;
     const float logu = logf(1.0f / (float)k);
     for (int e = threadIdx.x; e < yk; e += blockDim.x) {
@@ -189,6 +192,31 @@ __global__ __launch_bounds__(256) void latent_finalize_kernel(const float* __res
         scal[2] = stats[yk + 1] / rows;                         // non-mutual reg_kl               (sent_models.py:150-151)
         scal[3] = hq;
     }
+}
+
+__global__ __launch_bounds__(256) void latent_finalize_kernel(const float* __restrict__ stats, float Bg, int y, int k,
+                                                              float* __restrict__ scal, float* __restrict__ coef) {
+    __shared__ float s_kl[MAXE * 256], s_h[MAXE * 256];
+    latent_finalize_block(stats, Bg, y, k, scal, coef, s_kl, s_h);
+}
+
+// combine + finalize in ONE block (single-GPU path: no all-reduce sits between them): each statistic is summed over the
+// block partials by one wave exactly as latent_stats_combine_kernel does it (same lanes, same shuffle tree: same bits),
+// written to stats[] for the backward pass, and after a barrier the block runs the finalize arithmetic on them.
+__global__ __launch_bounds__(256) void latent_combine_finalize_kernel(const float* __restrict__ ws, int nblk, float* stats,
+                                                                      float Bg, int y, int k, float* __restrict__ scal,
+                                                                      float* __restrict__ coef) {
+    __shared__ float s_kl[MAXE * 256], s_h[MAXE * 256];
+    const int n = y * k + 2, lane = threadIdx.x & 63;
+    for (int e = threadIdx.x >> 6; e < n; e += 4) {
+        float s = 0.f;
+        for (int b = lane; b < nblk; b += 64) s += ws[(int64_t)b * n + e];
+        s = wave_sum(s);
+        if (lane == 0) stats[e] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    latent_finalize_block(stats, Bg, y, k, scal, coef, s_kl, s_h);
 }
 
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ log_qy, const float* __restrict__ coef,
@@ -313,10 +341,26 @@ extern "C" int laed_gumbel_latent_fwd(const float* logits, const float* u, int64
     if (R == 0) return 0;
     LAED_CHECK_ARG(logits && ((u && y) || log_qy), "gumbel_latent_fwd: null pointer");
 #define CALL(W) hipLaunchKernelGGL((gumbel_latent_fwd_kernel<W>), dim3((unsigned)cdiv64(R, 256 / W)), dim3(256), 0, \
-                                   (hipStream_t)stream, logits, u, R, k, tau, hard, y, ids, log_qy)
+                                   (hipStream_t)stream, logits, u, R, k, tau, hard, y, ids, log_qy, 0, (uint64_t)0, (uint64_t)0)
     DISPATCH_W(k, CALL);
 #undef CALL
     LAED_LAUNCH_CHECK("gumbel_latent_fwd");
+    return 0;
+}
+
+// The same kernel drawing its own uniforms (one launch instead of laed_uniform + laed_gumbel_latent_fwd): element (r, c)
+// uses draw `offset + r*k + c` of the counter RNG stream `seed`, so the sample equals the two-call form bit for bit.
+extern "C" int laed_gumbel_latent_fwd_rng(const float* logits, int64_t R, int k, float tau, int hard, uint64_t seed,
+                                          uint64_t offset, float* y, int64_t* ids, float* log_qy, void* stream) {
+    LAED_CHECK_ARG(R >= 0 && k > 0 && k <= 64, "gumbel_latent_fwd_rng: need 0 < k <= 64 (got %d)", k);
+    LAED_CHECK_ARG(tau > 0.f, "gumbel_latent_fwd_rng: temperature must be positive");
+    if (R == 0) return 0;
+    LAED_CHECK_ARG(logits && y, "gumbel_latent_fwd_rng: null pointer");
+#define CALL(W) hipLaunchKernelGGL((gumbel_latent_fwd_kernel<W>), dim3((unsigned)cdiv64(R, 256 / W)), dim3(256), 0, \
+                                   (hipStream_t)stream, logits, (const float*)nullptr, R, k, tau, hard, y, ids, log_qy, 1, seed, offset)
+    DISPATCH_W(k, CALL);
+#undef CALL
+    LAED_LAUNCH_CHECK("gumbel_latent_fwd_rng");
     return 0;
 }
 
@@ -388,6 +432,22 @@ extern "C" int laed_latent_stats_noalloc(const float* log_qy, int64_t B, int y, 
     LAED_LAUNCH_CHECK("latent_stats (noalloc)");
     hipLaunchKernelGGL(latent_stats_combine_kernel, dim3((yk + 2 + 3) / 4), dim3(256), 0, (hipStream_t)stream, ws, nblk, yk + 2, stats);
     LAED_LAUNCH_CHECK("latent_stats_combine (noalloc)");
+    return 0;
+}
+
+// laed_latent_stats + laed_latent_finalize for a job with no exchange between them (one GPU): two launches instead of
+// three, same bits (the combine step keeps its per-statistic wave reduction).
+extern "C" int laed_latent_stats_finalize(const float* log_qy, int64_t B, int y, int k, float* workspace, float* stats,
+                                          float* scal, float* coef, void* stream) {
+    LAED_CHECK_ARG(B > 0 && y > 0 && k > 0 && y * k <= MAXE * 256, "latent_stats_finalize: need y*k <= %d", MAXE * 256);
+    LAED_CHECK_ARG(log_qy && workspace && stats && scal, "latent_stats_finalize: null pointer");
+    const int yk = y * k;
+    const int nblk = (int)(B < STAT_BLOCKS ? B : STAT_BLOCKS);
+    hipLaunchKernelGGL(latent_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, B, yk, k, workspace);
+    LAED_LAUNCH_CHECK("latent_stats");
+    hipLaunchKernelGGL(latent_combine_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
+                       stats, (float)B, y, k, scal, coef);
+    LAED_LAUNCH_CHECK("latent_combine_finalize");
     return 0;
 }
 

@@ -87,6 +87,19 @@ __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ y, c
         y[i] = sc * x[i];
 }
 
+// y_t = s[0] * y_t for up to 8 tensors in one launch (the fused projection's dh / dW / db scaled by the incoming loss
+// gradient); a scale of exactly 1 -- the usual d loss of a train step -- moves nothing.
+struct ScaleMulti { float* y[8]; int64_t n[8]; int blk0[9]; int nt; };
+__global__ __launch_bounds__(256) void scale_dev_multi_kernel(ScaleMulti a, const float* __restrict__ s) {
+    const float sc = s[0];
+    if (sc == 1.0f) return;
+    int t = 0;
+    while (t + 1 < a.nt && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+    float* y = a.y[t];
+    const int64_t n = a.n[t], nb = a.blk0[t + 1] - a.blk0[t];
+    for (int64_t i = (int64_t)(blockIdx.x - a.blk0[t]) * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) y[i] = sc * y[i];
+}
+
 // torch.optim.SGD (momentum, dampening 0, no nesterov / weight decay) and torch.optim.RMSprop (alpha, eps, momentum,
 // not centred) as model_bases.py:126-133 builds them; same op order as torch's single-tensor path.  buf starts at zero
 // (mu*0 + g equals torch's first-step clone of g).
@@ -168,6 +181,26 @@ extern "C" int laed_adam_step_multi(int ntensors, float* const* p, const float* 
         hipLaunchKernelGGL(adam_multi_kernel, dim3(a.blk0[a.nt]), dim3(256), 0, (hipStream_t)stream, a, c);
         LAED_LAUNCH_CHECK("adam_step_multi");
     }
+    return 0;
+}
+
+extern "C" int laed_scale_by_dev_multi(int ntensors, float* const* y, const int64_t* n, const float* s, void* stream) {
+    LAED_CHECK_ARG(ntensors >= 0 && ntensors <= 8, "scale_by_dev_multi: at most 8 tensors per call");
+    LAED_CHECK_ARG(ntensors == 0 || (y && n && s), "scale_by_dev_multi: null pointer");
+    ScaleMulti a;
+    a.nt = 0;
+    a.blk0[0] = 0;
+    for (int t = 0; t < ntensors; ++t) {
+        LAED_CHECK_ARG(n[t] >= 0, "scale_by_dev_multi: negative size");
+        if (n[t] == 0) continue;
+        LAED_CHECK_ARG(y[t], "scale_by_dev_multi: null pointer");
+        const int k = a.nt++;
+        a.y[k] = y[t]; a.n[k] = n[t];
+        a.blk0[k + 1] = a.blk0[k] + grid_for(n[t]);
+    }
+    if (a.nt == 0) return 0;
+    hipLaunchKernelGGL(scale_dev_multi_kernel, dim3(a.blk0[a.nt]), dim3(256), 0, (hipStream_t)stream, a, s);
+    LAED_LAUNCH_CHECK("scale_by_dev_multi");
     return 0;
 }
 

@@ -307,6 +307,47 @@ __global__ __launch_bounds__(1024) void dot_kernel(const float* __restrict__ a, 
 
 // Dense log-prob input (NLLEntropy handed a materialised [N,V] tensor, criterions.py:43-72): label gather and its
 // scatter gradient.  A label outside [0,V) that is not the ignore index poisons its row with NaN (F.nll_loss raises).
+// Everything NLLEntropy needs from the labels in ONE single-block launch (criterions.py:43-72): the per-row loss weights of
+// the averaging mode, the labels in the order the consumer wants (time-major for the fused projection, batch-first for a
+// dense log-prob tensor) and this rank's non-PAD count.  mode: 0 = sum (weights 1), 1 = 'seq' (1/denom), 2 = 'real_word'
+// (1 / (sign(labels).sum(row) * denom), criterions.py:62), 3 = 'word' (1 / count; count = gcount[0] when the caller has
+// already all-reduced it, else this batch's own non-PAD count).  denom = B * world size.
+__global__ __launch_bounds__(1024) void nll_prepare_kernel(const int64_t* __restrict__ labels, int64_t ld, int B, int T,
+                                                           int64_t pad, int mode, float denom, const float* __restrict__ gcount,
+                                                           int time_major, int64_t* __restrict__ labels_out,
+                                                           float* __restrict__ scale_out, float* __restrict__ local_count) {
+    __shared__ int s_cnt;
+    extern __shared__ float s_row[];               // mode 2: per-sequence weights
+    const int64_t n = (int64_t)B * T;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if ((mode == 3 && gcount == nullptr) || local_count != nullptr) {
+        int c = 0;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) c += labels[(i / T) * ld + (i % T)] != pad ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((threadIdx.x & 63) == 0 && c != 0) atomicAdd(&s_cnt, c);       // integer: exact, order-free
+    }
+    if (mode == 2) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            int c = 0;
+            for (int t = 0; t < T; ++t) { const int64_t l = labels[(int64_t)b * ld + t]; c += (l > 0) - (l < 0); }   // torch.sign
+            s_row[b] = 1.0f / ((float)c * denom);
+        }
+    }
+    __syncthreads();
+    float w = 1.0f;
+    if (mode == 1) w = 1.0f / denom;
+    else if (mode == 3) w = 1.0f / (gcount != nullptr ? gcount[0] : (float)s_cnt);
+    if (threadIdx.x == 0 && local_count != nullptr) local_count[0] = (float)s_cnt;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int b = (int)(i / T), t = (int)(i - (int64_t)b * T);
+        const int64_t o = time_major ? (int64_t)t * B + b : i;
+        if (labels_out != nullptr) labels_out[o] = labels[(int64_t)b * ld + t];
+        scale_out[o] = mode == 2 ? s_row[b] : w;
+    }
+}
+
 __global__ __launch_bounds__(256) void nll_gather_fwd_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ labels,
                                                              int64_t N, int V, int64_t pad_id, float* __restrict__ tok) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
@@ -569,6 +610,18 @@ extern "C" int laed_nll_reduce(const float* tok_nll, const int64_t* labels, int6
     LAED_CHECK_ARG(tok_nll && labels && out, "nll_reduce: null pointer");
     hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tok_nll, labels, N, pad_id, out);
     LAED_LAUNCH_CHECK("nll_reduce");
+    return 0;
+}
+
+extern "C" int laed_nll_prepare(const int64_t* labels, int64_t ld, int B, int T, int64_t pad_id, int avg_mode, double denom,
+                                const float* global_count, int time_major, int64_t* labels_out, float* scale_out,
+                                float* local_count, void* stream) {
+    LAED_CHECK_ARG(B > 0 && T > 0 && ld >= T && avg_mode >= 0 && avg_mode <= 3 && denom > 0, "nll_prepare: bad argument");
+    LAED_CHECK_ARG(labels && scale_out, "nll_prepare: null pointer");
+    LAED_CHECK_ARG(avg_mode != 2 || B <= 8192, "nll_prepare: 'real_word' supports at most 8192 sequences per call");
+    hipLaunchKernelGGL(nll_prepare_kernel, dim3(1), dim3(1024), avg_mode == 2 ? (size_t)B * sizeof(float) : 0, (hipStream_t)stream,
+                       labels, ld, B, T, pad_id, avg_mode, (float)denom, global_count, time_major, labels_out, scale_out, local_count);
+    LAED_LAUNCH_CHECK("nll_prepare");
     return 0;
 }
 

@@ -27,6 +27,7 @@ _SIGS = {
     "laed_last_error": ([], ctypes.c_char_p),
     "laed_sgemm": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p], _i),
     "laed_embed_gather": ([_p, _i64, _p, _i, _i, _p, _f, _p, _p], _i),
+    "laed_embed_gather_bt": ([_p, _i64, _i, _i, _p, _i, _i, _p, _i, _f, _u64, _u64, _p, _p, _p, _p], _i),
     "laed_embed_scatter_add": ([_p, _i64, _p, _i, _i, _p, _f, _i64, _p, _p, _i64, _p], _i),
     "laed_embed_scatter_workspace": ([_i64, _i, _i], _i64),
     "laed_dropout_keep_mask": ([_p, _i64, _f, _u64, _u64, _p], _i),
@@ -41,11 +42,13 @@ _SIGS = {
     "laed_gru_bwd_workspace": ([_i, _i, _i, _i], _i64),
     "laed_sgemm_ws": ([_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i64, _p], _i),
     "laed_gumbel_latent_fwd": ([_p, _p, _i64, _i, _f, _i, _p, _p, _p, _p], _i),
+    "laed_gumbel_latent_fwd_rng": ([_p, _i64, _i, _f, _i, _u64, _u64, _p, _p, _p, _p], _i),
     "laed_gumbel_latent_bwd": ([_p, _p, _p, _p, _i64, _i, _f, _p, _p], _i),
     "laed_latent_stats_blocks": ([], _i),
     "laed_latent_stats": ([_p, _i64, _i, _i, _p, _p, _p], _i),
     "laed_latent_stats_noalloc": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_latent_finalize": ([_p, _d, _i, _i, _p, _p, _p], _i),
+    "laed_latent_stats_finalize": ([_p, _i64, _i, _i, _p, _p, _p, _p, _p], _i),
     "laed_latent_mi_coef": ([_p, _d, _i, _i, _p, _p], _i),
     "laed_latent_bwd": ([_p, _p, _p, _i, _i64, _d, _i, _i, _p, _i, _p], _i),
     "laed_avg_log_fwd": ([_p, _d, _i, _p, _p], _i),
@@ -64,6 +67,7 @@ _SIGS = {
     "laed_log_softmax_rows_bwd": ([_p, _i64, _p, _i64, _i64, _i, _p, _i64, _p], _i),
     "laed_argmax_rows": ([_p, _i64, _i, _i, _p, _p], _i),
     "laed_nll_reduce": ([_p, _p, _i64, _i64, _p, _p], _i),
+    "laed_nll_prepare": ([_p, _i64, _i, _i, _i64, _i, _d, _p, _i, _p, _p, _p, _p], _i),
     "laed_nll_gather_fwd": ([_p, _i64, _p, _i64, _i, _i64, _p, _p], _i),
     "laed_nll_gather_bwd": ([_p, _p, _p, _i64, _i, _i64, _p, _i64, _p], _i),
     "laed_attn_score_fwd": ([_p, _p, _p, _i64, _i, _p, _p], _i),
@@ -78,6 +82,7 @@ _SIGS = {
     "laed_rmsprop_step": ([_p, _p, _p, _p, _i64, _d, _d, _d, _d, _f, _p], _i),
     "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),
     "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),
+    "laed_scale_by_dev_multi": ([_i, _p, _p, _p, _p], _i),
     "laed_prof_enable": ([_i], _i),
     "laed_prof_reserve": ([_i], _i),
     "laed_prof_collect": ([ctypes.POINTER(ctypes.c_double)], _i),

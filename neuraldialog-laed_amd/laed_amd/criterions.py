@@ -28,6 +28,8 @@ class NLLEntropy(_Loss):
     def local_count(self, labels_bf):
         """This rank's non-PAD target count as a 1-element float tensor: the per-rank sum a model folds into its one
         forward exchange (BatchPriorKL(..., extra=...)) so that 'word' needs no collective of its own."""
+        if labels_bf.is_cuda and labels_bf.dim() == 2:
+            return ops.nll_prepare(labels_bf, self.padding_idx, None, 1, want_local_count=True)[2]
         return (labels_bf != self.padding_idx).sum().float().reshape(1)
 
     def _row_scale(self, labels_bf, B, T, global_count=None):
@@ -55,18 +57,29 @@ class NLLEntropy(_Loss):
         device tensor when the caller has already exchanged it (data parallelism, 'word' averaging)."""
         from .enc2dec.decoders import LazyLogProbs
         B, T = labels.shape[0], labels.shape[1]
+        # one launch for everything derived from the labels (weights of the averaging mode, re-ordered labels); the torch
+        # composition below it remains for 'word' under data parallelism when the caller has NOT exchanged the count
+        fused = labels.is_cuda and (self.avg_type != 'word' or global_count is not None or parallel.group() is None)
         if isinstance(net_output, LazyLogProbs):
-            scale_tm = self._row_scale(labels, B, T, global_count).t().contiguous().view(-1)
-            labels_tm = labels.t().contiguous().view(-1)
+            if fused:
+                labels_tm, scale_tm, _ = ops.nll_prepare(labels, self.padding_idx, self.avg_type, parallel.world_size(),
+                                                         global_count, time_major=True)
+            else:
+                scale_tm = self._row_scale(labels, B, T, global_count).t().contiguous().view(-1)
+                labels_tm = labels.t().contiguous().view(-1)
             loss, tok = ops.ProjNLLFunction.apply(net_output.h_tm.reshape(B * T, -1), net_output.project.weight,
                                                   net_output.project.bias, labels_tm, scale_tm, self.padding_idx,
                                                   torch.is_grad_enabled())
             net_output.tok_nll = tok.view(T, B).t()
             return loss
         # a materialised [B,T,V] log-prob tensor: label gather + weighted sum on the HIP kernels (batch-first rows)
-        scale_bf = self._row_scale(labels, B, T, global_count).contiguous().view(-1)
-        loss, _tok = ops.NLLGatherFunction.apply(net_output.reshape(B * T, -1), labels.reshape(-1).contiguous(), scale_bf,
-                                                 self.padding_idx)
+        if fused:
+            labels_bf, scale_bf, _ = ops.nll_prepare(labels, self.padding_idx, self.avg_type, parallel.world_size(),
+                                                     global_count, time_major=False)
+        else:
+            scale_bf = self._row_scale(labels, B, T, global_count).contiguous().view(-1)
+            labels_bf = labels.reshape(-1).contiguous()
+        loss, _tok = ops.NLLGatherFunction.apply(net_output.reshape(B * T, -1), labels_bf, scale_bf, self.padding_idx)
         return loss
 
 

@@ -113,10 +113,18 @@ class DecoderRNN(BaseRNN):
     def forward_step(self, input_var, hidden, encoder_outputs=None):
         """[B,T] ids, hidden [1,B,H] -> (lazy log-probs over [B,T,V], hidden [1,B,H], None)."""
         B, T = input_var.size(0), input_var.size(1)
-        keep, p = None, 0.0
+        keep, p, rng = None, 0.0, None
         if self.training and self.input_dropout_p > 0:
-            keep, p = self._keep_mask_tm(B, T, input_var.device), self.input_dropout_p
-        embedded = self.embedding(input_var, keep=keep, drop_p=p)       # gather + dropout fused
+            p = self.input_dropout_p
+            if self.injected_keep is not None:
+                keep = self._keep_mask_tm(B, T, input_var.device)        # tests: a recorded mask
+            else:
+                # the keep decisions are drawn inside the gather kernel (same counter RNG stream and element index as
+                # _keep_mask_tm: the GLOBAL batch row keys it, so a DP job drops what the single-GPU job drops)
+                rng = ((self.drop_seed * 1000003 + 2 * self.drop_step + 1) & 0xFFFFFFFFFFFFFFFF,
+                       parallel.rank() * B * T * self.input_size)
+                self.drop_step += 1
+        embedded = self.embedding(input_var, keep=keep, drop_p=p, rng=rng)      # ids transpose + dropout + gather fused
         out_tm, hT = self.rnn.forward_tm(embedded.transpose(0, 1), None if hidden is None else hidden[0])
         return LazyLogProbs(out_tm, self.project, B), hT.unsqueeze(0), None
 

@@ -115,7 +115,7 @@ class DiVAE(_SentBase):
         out_utts = self.np2var(data_feed['outputs'], LONG)
         log_qy, y_ids, dec_init_state = self._encode_latent(out_utts, 1.0)
 
-        labels = out_utts[:, 1:].contiguous()
+        labels = out_utts[:, 1:]            # a strided view: the loss kernels read it in place
         dec_inputs = out_utts[:, 0:-1]
         if mode != GEN:
             # the latent losses have no random draw and no consumer on the decoder side: computing them first lets their
@@ -125,7 +125,7 @@ class DiVAE(_SentBase):
         dec_outs, dec_last, dec_ctx = self.decoder(batch_size, dec_inputs, dec_init_state, mode=mode,
                                                    gen_type=gen_type, beam_size=self.beam_size)
         if mode == GEN:
-            return dec_ctx, labels
+            return dec_ctx, labels.contiguous()
         nll = self.nll_loss(dec_outs, labels, global_count=count)
         self._last_dec_outs = dec_outs
         results = Pack(nll=nll, reg_kl=reg_kl, mi=mi, bpr=b_pr)
@@ -227,8 +227,8 @@ class DiVST(_SentBase):
         next_utts = self.np2var(data_feed['nexts'], LONG)
         log_qy, y_ids, dec_init_state = self._encode_latent(out_utts, self.kl_w)
 
-        prev_labels = prev_utts[:, 1:].contiguous()
-        next_labels = next_utts[:, 1:].contiguous()
+        prev_labels = prev_utts[:, 1:] if mode != GEN else prev_utts[:, 1:].contiguous()
+        next_labels = next_utts[:, 1:] if mode != GEN else next_utts[:, 1:].contiguous()
         prev_count = next_count = None
         if mode != GEN:                                  # one exchange for the statistics and both target counts
             (reg_kl, b_pr, mi), (prev_count, next_count) = self._latent_losses(log_qy, [prev_labels, next_labels])

@@ -28,13 +28,17 @@ class Embedding(nn.Embedding):
     keep [T,B,E] uint8 (time-major), drop_p.
     """
 
-    def forward(self, ids, keep=None, drop_p=0.0):
+    def forward(self, ids, keep=None, drop_p=0.0, rng=None):
+        """keep: injected keep mask, TIME-major [T,B,E] uint8; rng = (seed, offset): the dropout decisions are drawn
+        inside the gather kernel from the counter RNG (element (b,t,e) = draw offset + (b*T+t)*E + e)."""
         pad = -1 if self.padding_idx is None else self.padding_idx
         if ids.dim() == 1:
             return ops.EmbedFunction.apply(self.weight, ids.contiguous(), keep, drop_p, pad)
         B, T = ids.shape
-        ids_tm = ids.t().contiguous().view(-1)
-        out = ops.EmbedFunction.apply(self.weight, ids_tm, keep, drop_p, pad)
+        if ids.stride(1) != 1:
+            ids = ids.contiguous()
+        # one launch: ids transposed to time-major, dropout decisions, gather (the ids need not be contiguous rows)
+        out = ops.EmbedBTFunction.apply(self.weight, ids, keep, rng, drop_p, pad)
         return out.view(T, B, self.embedding_dim).transpose(0, 1)
 
 
@@ -92,9 +96,20 @@ class GumbelConnector(nn.Module):
         self.step += 1
         return u.view(R, k)
 
+    def _rng_for(self, logits):
+        """(seed, offset) of the draws sample_uniform(logits) would make, advancing the step the same way."""
+        R, k = logits.shape
+        row0 = parallel.rank() * R
+        rng = ((self.seed * 1000003 + 2 * self.step) & 0xFFFFFFFFFFFFFFFF, row0 * k)
+        self.step += 1
+        return rng
+
     def forward(self, logits, temperature, use_gpu=True, hard=False, return_max_id=False, return_log_qy=False):
-        u = self.sample_uniform(logits)
-        y, log_qy, ids = ops.GumbelLatentFunction.apply(logits, u, float(temperature), bool(hard))
+        if 'sample_uniform' in self.__dict__ or type(self).sample_uniform is not GumbelConnector.sample_uniform:
+            u, rng = self.sample_uniform(logits), None       # injected / overridden noise source: replay its uniforms
+        else:
+            u, rng = None, self._rng_for(logits)             # default: drawn inside the kernel, no [R,k] tensor of uniforms
+        y, log_qy, ids = ops.GumbelLatentFunction.apply(logits, u, float(temperature), bool(hard), rng)
         ret = (y,)
         if return_max_id:
             ret += (ids.view(-1, 1),)

@@ -107,6 +107,42 @@ def nll_reduce(tok_nll, labels, pad_id):
     return out
 
 
+_AVG_MODES = {None: 0, 'seq': 1, 'real_word': 2, 'word': 3}
+
+
+def nll_prepare(labels, pad_id, avg_type, world, global_count=None, time_major=True, want_local_count=False):
+    """labels [B,T] int64 (batch-first view, unit column stride) -> (labels_out [B*T], scale_out [B*T], local_count|None):
+    NLLEntropy's per-row weights, re-ordered labels and non-PAD count in one launch (laed_nll_prepare)."""
+    if avg_type not in _AVG_MODES:
+        raise ValueError("Unknown avg type")
+    if labels.dim() != 2 or labels.stride(1) != 1 or labels.dtype != I64:
+        labels = labels.long().contiguous()
+    B, T = labels.shape
+    dev = labels.device
+    import ctypes
+    if not labels.is_cuda:
+        raise _lib.LaedError("laed_amd kernels need CUDA (ROCm) tensors; got a CPU tensor")
+    labels_out = torch.empty(B * T, device=dev, dtype=I64)
+    scale_out = torch.empty(B * T, device=dev, dtype=torch.float32)
+    local = torch.empty(1, device=dev, dtype=torch.float32) if want_local_count else None
+    check(lib.laed_nll_prepare(ctypes.c_void_p(labels.data_ptr()), labels.stride(0) if B > 1 else max(T, 1), B, T, int(pad_id),
+                               _AVG_MODES[avg_type], float(B * world), ptr(global_count), int(bool(time_major)),
+                               ptr(labels_out, I64), ptr(scale_out), ptr(local), stream()), "laed_nll_prepare")
+    return labels_out, scale_out, local
+
+
+def scale_by_dev_multi_(tensors, g):
+    """t *= g[0] for every tensor of the list, one launch (nothing moves when g[0] == 1)."""
+    import ctypes
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    for i in range(0, len(ts), 8):
+        grp = ts[i:i + 8]
+        n = len(grp)
+        arr = (ctypes.c_void_p * n)(*[ptr(t).value for t in grp])
+        sizes = (ctypes.c_int64 * n)(*[t.numel() for t in grp])
+        check(lib.laed_scale_by_dev_multi(n, arr, sizes, ptr(g), stream()), "laed_scale_by_dev_multi")
+
+
 def proj_ldl(V):
     return int(lib.laed_proj_nll_ldl(int(V)))
 
@@ -318,6 +354,48 @@ class EmbedFunction(torch.autograd.Function):
         return dw, None, None, None, None
 
 
+class EmbedBTFunction(torch.autograd.Function):
+    """ids [B,T] (batch-first, any row stride) -> out [T*B,E] TIME-major rows, in one launch: the ids' transposition, the
+    input-dropout decisions (an injected time-major mask `keep_in`, or `rng` = (seed, offset) of the counter RNG keyed by
+    the batch-first element index, or none) and the gather.  The transposed ids and the mask are kept for backward."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, keep_in, rng, drop_p, pad_id):
+        if ids.dim() != 2 or ids.stride(1) != 1 or ids.dtype != I64:
+            raise _lib.LaedError("embed: ids must be an int64 [B,T] tensor with unit column stride")
+        B, T = ids.shape
+        V, E = weight.shape
+        dev = weight.device
+        out = torch.empty((T * B, E), device=dev, dtype=torch.float32)
+        ids_tm = torch.empty(T * B, device=dev, dtype=I64)
+        dropping = drop_p > 0.0 and (keep_in is not None or rng is not None)
+        keep_out = torch.empty(T * B * E, device=dev, dtype=U8) if (dropping and keep_in is None) else None
+        seed, off = rng if (rng is not None and keep_in is None) else (0, 0)
+        import ctypes
+        check(lib.laed_embed_gather_bt(ctypes.c_void_p(ids.data_ptr()), ids.stride(0) if B > 1 else max(T, 1), B, T, ptr(weight),
+                                       V, E, ptr(keep_in, U8) if dropping else None, int(dropping and keep_in is None),
+                                       float(drop_p) if dropping else 0.0, seed, off, ptr(out), ptr(ids_tm, I64),
+                                       ptr(keep_out, U8), stream()), "laed_embed_gather_bt")
+        keep = (keep_in if keep_in is not None else keep_out) if dropping else None
+        ctx.save_for_backward(ids_tm, keep)
+        ctx.meta = (V, E, float(drop_p) if dropping else 0.0, int(pad_id))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, keep = ctx.saved_tensors
+        V, E, p, pad_id = ctx.meta
+        dout = _f32c(dout)
+        dw = torch.zeros((V, E), device=dout.device, dtype=torch.float32)
+        ws_b = int(lib.laed_embed_scatter_workspace(ids.numel(), V, E))
+        ws = workspace("scatter", (ws_b + 3) // 4, dout.device) if ws_b > 0 else None
+        check(lib.laed_embed_scatter_add(ptr(ids, I64), ids.numel(), ptr(dout), V, E,
+                                         ptr(keep, U8) if keep is not None else None, p, pad_id, ptr(dw),
+                                         ptr(ws), ws_b, stream()),
+              "laed_embed_scatter_add")
+        return dw, None, None, None, None, None
+
+
 class LinearFunction(torch.autograd.Function):
     """y = x W^T + b on the fp32 MFMA GEMM; backward = two more GEMMs (+ bias grad as a column sum)."""
 
@@ -429,6 +507,7 @@ class GRUFunction(torch.autograd.Function):
         if keep:
             ctx.save_for_backward(x, w_ih, w_hh, hbuf, gates, hn)
         ctx.has_h0 = h0 is not None
+        ctx.set_materialize_grads(False)          # an unused output (encoder: out; decoder: hT) arrives as None, not zeros
         out = hbuf[1:]
         hT = hbuf[T]
         return out, hT
@@ -462,14 +541,19 @@ class GumbelLatentFunction(torch.autograd.Function):
     """logits[R,k], u[R,k] -> y (Gumbel-softmax sample or one-hot), log_qy = log_softmax(logits), ids[R]."""
 
     @staticmethod
-    def forward(ctx, logits, u, tau, hard):
+    def forward(ctx, logits, u, tau, hard, rng=None):
+        """u: uniforms [R,k] to replay, or None with rng = (seed, offset): drawn inside the kernel (same stream, same bits)."""
         logits = _f32c(logits)
         R, k = logits.shape
         y = torch.empty_like(logits)
         log_qy = torch.empty_like(logits)
         ids = torch.empty(R, device=logits.device, dtype=I64)
-        check(lib.laed_gumbel_latent_fwd(ptr(logits), ptr(_f32c(u)), R, k, float(tau), int(bool(hard)), ptr(y), ptr(ids, I64),
-                                         ptr(log_qy), stream()), "laed_gumbel_latent_fwd")
+        if u is None:
+            check(lib.laed_gumbel_latent_fwd_rng(ptr(logits), R, k, float(tau), int(bool(hard)), int(rng[0]), int(rng[1]),
+                                                 ptr(y), ptr(ids, I64), ptr(log_qy), stream()), "laed_gumbel_latent_fwd_rng")
+        else:
+            check(lib.laed_gumbel_latent_fwd(ptr(logits), ptr(_f32c(u)), R, k, float(tau), int(bool(hard)), ptr(y),
+                                             ptr(ids, I64), ptr(log_qy), stream()), "laed_gumbel_latent_fwd")
         ctx.save_for_backward(y, log_qy)
         ctx.meta = (float(tau), bool(hard))
         ctx.mark_non_differentiable(ids)
@@ -485,7 +569,7 @@ class GumbelLatentFunction(torch.autograd.Function):
         dlogits = torch.empty_like(y)
         check(lib.laed_gumbel_latent_bwd(ptr(y), ptr(dy), ptr(log_qy), ptr(dlq), R, k, tau, ptr(dlogits), stream()),
               "laed_gumbel_latent_bwd")
-        return dlogits, None, None, None
+        return dlogits, None, None, None, None
 
 
 class LatentLossFunction(torch.autograd.Function):
@@ -507,18 +591,23 @@ class LatentLossFunction(torch.autograd.Function):
         ne = 0 if extra is None else int(extra.numel())
         msg = torch.empty(n + ne, device=dev, dtype=torch.float32)
         stats = msg[:n]
-        check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
-        if ne:
-            msg[n:].copy_(extra.reshape(-1))
+        scal = torch.empty(4, device=dev, dtype=torch.float32)
+        coef = torch.empty(y_size * k, device=dev, dtype=torch.float32)
         Bg = float(B)
-        if group is not None:
+        if group is None:                                    # one GPU: nothing to exchange between statistics and losses
+            check(lib.laed_latent_stats_finalize(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), ptr(scal), ptr(coef), stream()),
+                  "laed_latent_stats_finalize")
+            if ne:
+                msg[n:].copy_(extra.reshape(-1))
+        else:
+            check(lib.laed_latent_stats(ptr(log_qy), B, y_size, k, ptr(ws), ptr(stats), stream()), "laed_latent_stats")
+            if ne:
+                msg[n:].copy_(extra.reshape(-1))
             import torch.distributed as dist
             from . import parallel
             parallel.all_reduce_(msg, group)
             Bg = float(B * dist.get_world_size(group))       # equal shards per rank
-        scal = torch.empty(4, device=dev, dtype=torch.float32)
-        coef = torch.empty(y_size * k, device=dev, dtype=torch.float32)
-        check(lib.laed_latent_finalize(ptr(stats), Bg, y_size, k, ptr(scal), ptr(coef), stream()), "laed_latent_finalize")
+            check(lib.laed_latent_finalize(ptr(stats), Bg, y_size, k, ptr(scal), ptr(coef), stream()), "laed_latent_finalize")
         ctx.save_for_backward(log_qy, coef, stats)
         ctx.meta = (B, Bg, y_size, k)
         ctx.set_materialize_grads(False)          # unused outputs (mi, row-KL in the default model) arrive as None
@@ -801,8 +890,7 @@ class ProjNLLFunction(torch.autograd.Function):
         _single_use(ctx, "ProjNLLFunction")
         dh, dW, db = ctx.saved_tensors
         g = _f32c(dloss).reshape(1)
-        for t in (dh, dW, db):
-            check(lib.laed_scale_by_dev(ptr(t), ptr(t), ptr(g), t.numel(), stream()), "laed_scale_by_dev")
+        scale_by_dev_multi_((dh, dW, db), g)
         return dh, dW, db, None, None, None, None
 
 

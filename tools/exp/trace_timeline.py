@@ -9,7 +9,7 @@ t0 = int(rows[0]['Start_Timestamp'])
 groups = []
 for r in rows:
     name = r['Kernel_Name']
-    name = name.replace('(anonymous namespace)::', '').replace('void ', '')[:64]
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')[:int(sys.argv[3]) if len(sys.argv) > 3 else 64]
     s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
     if groups and groups[-1][0] == name:
         g = groups[-1]; g[2] = e; g[3] += e - s; g[4] += 1
