@@ -176,14 +176,18 @@ __device__ __forceinline__ void latent_finalize_block(const float* stats, float 
         if (coef != nullptr) coef[e] = el * ((l - logu) + 1.0f) / (qbar + 1e-15f) / ((float)y * Bg);
     }
     __syncthreads();
+    // row sums (over the k classes, in class order) by one thread per latent variable, in place at the row's first slot;
+    // thread 0 then adds the rows in row order: the same association as one thread walking everything, y times shorter
+    for (int yy = threadIdx.x; yy < y; yy += blockDim.x) {
+        float a = 0.f, h = 0.f;
+        for (int c = 0; c < k; ++c) { a += s_kl[yy * k + c]; h += s_h[yy * k + c]; }
+        s_kl[yy * k] = a;
+        s_h[yy * k] = h;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         float bpr = 0.f, hq = 0.f;
-        for (int yy = 0; yy < y; ++yy) {
-            float a = 0.f, h = 0.f;
-            for (int c = 0; c < k; ++c) { a += s_kl[yy * k + c]; h += s_h[yy * k + c]; }
-            bpr += a;
-            hq += h;
-        }
+        for (int yy = 0; yy < y; ++yy) { bpr += s_kl[yy * k]; hq += s_h[yy * k]; }
         bpr /= (float)y;                                        // unit_average=True -> mean over the y rows
         hq /= (float)y;
         const float rows = (float)y * Bg;
@@ -203,16 +207,24 @@ __global__ __launch_bounds__(256) void latent_finalize_kernel(const float* __res
 // combine + finalize in ONE block (single-GPU path: no all-reduce sits between them): each statistic is summed over the
 // block partials by one wave exactly as latent_stats_combine_kernel does it (same lanes, same shuffle tree: same bits),
 // written to stats[] for the backward pass, and after a barrier the block runs the finalize arithmetic on them.
-__global__ __launch_bounds__(256) void latent_combine_finalize_kernel(const float* __restrict__ ws, int nblk, float* stats,
-                                                                      float Bg, int y, int k, float* __restrict__ scal,
-                                                                      float* __restrict__ coef) {
+__global__ __launch_bounds__(1024) void latent_combine_finalize_kernel(const float* __restrict__ ws, int nblk, float* stats,
+                                                                       float Bg, int y, int k, float* __restrict__ scal,
+                                                                       float* __restrict__ coef) {
     __shared__ float s_kl[MAXE * 256], s_h[MAXE * 256];
-    const int n = y * k + 2, lane = threadIdx.x & 63;
-    for (int e = threadIdx.x >> 6; e < n; e += 4) {
-        float s = 0.f;
-        for (int b = lane; b < nblk; b += 64) s += ws[(int64_t)b * n + e];
-        s = wave_sum(s);
-        if (lane == 0) stats[e] = s;
+    const int n = y * k + 2, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    // four statistics per wave and pass, so that their (dependent) load -> shuffle-tree chains overlap
+    for (int e0 = (threadIdx.x >> 6) * 4; e0 < n; e0 += nw * 4) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = lane; b < nblk; b += 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (e0 + j < n) s[j] += ws[(int64_t)b * n + e0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = wave_sum(s[j]);
+            if (lane == 0 && e0 + j < n) stats[e0 + j] = t;
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -445,7 +457,7 @@ extern "C" int laed_latent_stats_finalize(const float* log_qy, int64_t B, int y,
     const int nblk = (int)(B < STAT_BLOCKS ? B : STAT_BLOCKS);
     hipLaunchKernelGGL(latent_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, log_qy, B, yk, k, workspace);
     LAED_LAUNCH_CHECK("latent_stats");
-    hipLaunchKernelGGL(latent_combine_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
+    hipLaunchKernelGGL(latent_combine_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, nblk,
                        stats, (float)B, y, k, scal, coef);
     LAED_LAUNCH_CHECK("latent_combine_finalize");
     return 0;

@@ -125,7 +125,9 @@ class DecoderRNN(BaseRNN):
                        parallel.rank() * B * T * self.input_size)
                 self.drop_step += 1
         embedded = self.embedding(input_var, keep=keep, drop_p=p, rng=rng)      # ids transpose + dropout + gather fused
-        out_tm, hT = self.rnn.forward_tm(embedded.transpose(0, 1), None if hidden is None else hidden[0])
+        # hidden [1,B,H] -> [B,H] as a VIEW (hidden[0] is a select: its backward is a zero-fill plus a copy launch)
+        h0 = None if hidden is None else hidden.reshape(hidden.shape[-2], hidden.shape[-1])
+        out_tm, hT = self.rnn.forward_tm(embedded.transpose(0, 1), h0)
         return LazyLogProbs(out_tm, self.project, B), hT.unsqueeze(0), None
 
     def _beam_search(self, batch_size, init_state, beam_size):

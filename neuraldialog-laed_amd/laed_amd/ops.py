@@ -212,8 +212,8 @@ def proj_nll_raw(h, W, b, labels, row_scale, pad_id, with_grad, chunk_rows=None)
         dW = torch.empty_like(W)
         db = torch.empty(V, device=dev, dtype=torch.float32)
     check(lib.laed_proj_nll(ptr(h), ptr(W), ptr(b), ptr(labels, I64), ptr(row_scale), N, H, V, int(pad_id),
-                            int(with_grad), 0, ptr(ws), ws_n, int(chunk_rows), ptr(tok), ptr(lse), ptr(dh), ptr(dW), ptr(db),
-                            stream()), "laed_proj_nll")
+                            int(with_grad), 0, ptr(ws), ws_n, int(chunk_rows), ptr(tok), ptr(lse),
+                            ptr(dh), ptr(dW), ptr(db), stream()), "laed_proj_nll")
     return tok, lse, dh, dW, db
 
 
@@ -557,6 +557,7 @@ class GumbelLatentFunction(torch.autograd.Function):
         ctx.save_for_backward(y, log_qy)
         ctx.meta = (float(tau), bool(hard))
         ctx.mark_non_differentiable(ids)
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None, not as a zero-filled tensor
         return y, log_qy, ids
 
     @staticmethod
