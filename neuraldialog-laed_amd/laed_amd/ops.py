@@ -462,9 +462,17 @@ def _cu_budget(device):
         # recurrence to the per-step launches (82 ms per step in the same rehearsal).
         return 1
     n = _CU_SHARE["streams"]
-    if n <= 1:
+    from . import parallel
+    dp = parallel.group() is not None
+    if n <= 1 and not dp:
         return 0                                            # the whole device
-    return max(1, torch.cuda.get_device_properties(device).multi_processor_count // n)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if dp:
+        # Data parallelism: the gradient reducer's RCCL kernels (one workgroup per channel, up to a few dozen) run on
+        # their own stream beside the backward recurrences.  A persistent grid sized to every CU would have to wait for
+        # them to leave (bounded, but a wait of seconds that ends in poisoned outputs); a quarter of the CUs is left free.
+        cus = (cus * 3) // 4
+    return max(1, cus // max(n, 1))
 
 
 def gru_persist_timeouts():

@@ -418,6 +418,13 @@ def test_persistent_recurrence_budget_streams_divide_processes_forbid(monkeypatc
         assert ops._cu_budget(0) == 1
     ops.set_device_sharers(1)
     assert ops._cu_budget(0) == 0
+    # data parallelism: a quarter of the CUs stays free for the gradient reducer's RCCL kernels
+    from laed_amd import parallel
+    monkeypatch.setattr(parallel, "_ENABLED", True)
+    monkeypatch.setattr(parallel, "_GROUP", object())
+    assert ops._cu_budget(0) == 192
+    with ops.concurrent_streams(2):
+        assert ops._cu_budget(0) == 96
 
 
 # ---- the same engine, PINNED against the reference's own train() / validate() / LossManager ---------------------------

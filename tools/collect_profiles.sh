@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): every measurement profiles/ is built from, into gpurun_out/final/.
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
-# then, back in the build container:  python tools/publish_profiles.py r2
+# then, back in the build container:  python tools/publish_profiles.py r3
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
@@ -26,5 +26,12 @@ done
 step timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_fetch.log 2>&1
 step timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_write.log 2>&1
 step timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_mfma.log 2>&1
+step timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_hit -- python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0 --no-prof > $O/pmc_hit.log 2>&1
+# 4. launch-by-launch view of one step of the reference's own script shapes (tools/exp/trace_step.py)
+for w in P-fixed VST-fixed; do
+  python tools/exp/trace_step.py $O/prof_$w > $O/step_$w.txt 2>&1 || true
+done
+# 5. the N > 1 path on this one GPU (rehearsal: gloo, two ranks share the device), started by bench.py itself
+step timeout -k 10 300 python bench.py --gpus 2 --backend gloo --global-batch 128 --steps 5 --warmup 2 --no-alt > $O/bench_dp2_rehearsal.json 2> $O/bench_dp2_rehearsal.err
 rm -f $O/*/*/*kernel_trace.csv        # large; the stats CSV is what profiles/ keeps
 echo done

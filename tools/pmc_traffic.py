@@ -30,6 +30,35 @@ VARIANT_OF = [   # same order as bench.py VARIANTS / laed_prof_collect
 ]
 
 
+# The projection products of the S-fixed job (V = 50000, H = 1024, 40960-row chunks), by (variant, workgroups of the launch):
+# (M, N, K) -> algorithmic bytes (every operand read once, the result written once; dW is read-modify-write) and the bytes
+# THIS TILING needs at best: 128x128 tiles, 8 x 8 tiles resident per XCD, so the long operand is read once and the short
+# one (N = 1024 wide) once per group of 8 row tiles.  A measured figure well above the second number means the blocks of
+# a group have drifted out of phase and re-fetch strips their group already evicted.
+KNOWN_SHAPES = {
+    ("sgemm_128x128_NT", 125120): ("logits = h W^T + b", 40960, 50000, 1024),
+    ("sgemm_128x128_NN", 2560): ("dh = dl W", 40960, 1024, 50000),
+    ("sgemm_128x128_TN", 3072): ("dW += dl^T h (whole-rounds part)", 49152, 1024, 40960),
+}
+
+
+def shape_bytes(variant, workgroups):
+    k = KNOWN_SHAPES.get((variant, workgroups))
+    if k is None:
+        return None
+    what, M, N, K = k
+    if variant.endswith("NT"):      # both operands short (0.37 GB), the [M][ldl] tile written
+        algo = 4.0 * (M * K + N * K + M * 50016)
+        ideal = algo
+    elif variant.endswith("NN"):
+        algo = 4.0 * (M * K + K * N + M * N)
+        ideal = 4.0 * (M * K + (M // 128 // 8) * K * N + M * N)
+    else:
+        algo = 4.0 * (K * M + K * N + 2 * M * N)
+        ideal = 4.0 * (K * M + (M // 128 // 8) * K * N + 2 * M * N)
+    return {"product": what, "M": M, "N": N, "K": K, "algorithmic_bytes": round(algo), "tiling_ideal_bytes": round(ideal)}
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
@@ -69,6 +98,12 @@ def main():
             # a variant covers dissimilar launches (the projection product, its split-K tail, the GRU products): the
             # average over them means little, so the launch shape that moves the most bytes is reported on its own
             top = max(sel, key=lambda r: (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"])
+            extra = {}
+            sb = shape_bytes(vname, top["workgroups"])
+            if sb is not None:
+                moved = top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"]
+                extra = dict(sb, ratio_to_algorithmic=round(moved / sb["algorithmic_bytes"], 2),
+                             ratio_to_tiling_ideal=round(moved / sb["tiling_ideal_bytes"], 2))
             variants[vname] = {
                 "launches": n,
                 "bytes_per_launch": round(sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"]
@@ -76,13 +111,18 @@ def main():
                 "largest_launch": {"workgroups": top["workgroups"], "launches": top["launches"],
                                    "fetch_bytes_per_launch": top["fetch_bytes_per_launch"],
                                    "write_bytes_per_launch": top["write_bytes_per_launch"],
-                                   "bytes_per_launch": top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"]}}
+                                   "bytes_per_launch": top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"],
+                                   **extra}}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
                          "`python bench.py --steps 2 --warmup 1 --no-alt --cpu-sample 0`",
                "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950, 16 B/lane reads); includes Infinity-Cache hits",
                "variants": variants, "kernels": rows[:40]}, open(out, "w"), indent=1)
     for v, d in variants.items():
-        print("%-26s launches=%5d  %.3f GB/launch" % (v, d["launches"], d["bytes_per_launch"] / 1e9))
+        ll = d["largest_launch"]
+        print("%-26s launches=%5d  %.3f GB/launch  largest: %.2f GB%s" % (
+            v, d["launches"], d["bytes_per_launch"] / 1e9, ll["bytes_per_launch"] / 1e9,
+            "  = %.2fx algorithmic, %.2fx this tiling's best" % (ll["ratio_to_algorithmic"], ll["ratio_to_tiling_ideal"])
+            if "ratio_to_algorithmic" in ll else ""))
 
 
 if __name__ == "__main__":

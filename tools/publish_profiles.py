@@ -30,5 +30,10 @@ subprocess.check_call([py, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.pat
                        os.path.join(SRC, "pmc_write"), os.path.join(DST, rnd + "_pmc_traffic.json")])
 subprocess.check_call([py, os.path.join(ROOT, "tools", "pmc_mfma.py"), os.path.join(SRC, "pmc_mfma"),
                        os.path.join(DST, rnd + "_pmc_mfma.json")])
+for extra in ("step_P-fixed.txt", "step_VST-fixed.txt"):
+    if os.path.exists(os.path.join(SRC, extra)):
+        shutil.copy(os.path.join(SRC, extra), os.path.join(DST, "%s_%s" % (rnd, extra)))
+if os.path.exists(os.path.join(SRC, "bench_dp2_rehearsal.json")):
+    json.dump(json_line(os.path.join(SRC, "bench_dp2_rehearsal.json")), open(os.path.join(DST, rnd + "_bench_dp2_rehearsal.json"), "w"), indent=1)
 subprocess.check_call([py, os.path.join(ROOT, "tools", "hbm_kernels.py"), os.path.join(SRC, "prof_S-fixed"),
                        os.path.join(DST, rnd + "_hbm_kernels.json")])
