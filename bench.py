@@ -52,7 +52,7 @@ SHAPES = {
 DIALOG_CTX = 10
 
 
-TRAFFIC_NOTE = ("profiles/r2_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+TRAFFIC_NOTE = ("profiles/r3_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                 "(tools/pmc_traffic.py; KiB*1024, FETCH doubled per the gfx950 note), L2<->fabric bytes per launch of the "
                 "variant's largest launch shape (the projection product; algorithmic bytes of that launch: dW TN 8.4 GB, "
                 "dh NN 8.4 GB, logits NT 8.6 GB with 40960-row chunks), Infinity-Cache hits included; committed file, not "
@@ -62,7 +62,7 @@ TRAFFIC_NOTE = ("profiles/r2_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRIT
 def pmc_traffic(variant, same_job):
     """Per-launch L2<->fabric bytes of `variant` from the committed PMC passes of this same job (S-fixed, 1 GPU);
     None for any other job (the counters cannot be collected inside a normal run)."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
     if not same_job or not os.path.exists(path):
         return None
     try:

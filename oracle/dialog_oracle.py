@@ -2,7 +2,7 @@
 
 Same rules as laed_oracle.py: imported only by tests/ (and smoke / bench baselines), never by the product.
 A fresh fp32 torch-CPU restatement of laed/models/dialog_models.py (paths relative to /root/reference), PINNED by
-tests/golden/{aeed_tiny,aeed_mid,sted_tiny}.npz which were produced by running the reference itself
+tests/golden/{aeed_tiny,aeed_mid,sted_tiny,sted_mid}.npz which were produced by running the reference itself
 (tests/golden/make_goldens_dialog.py).  tests/test_oracle_dialog_vs_golden.py checks it against those files.
 """
 import math
