@@ -412,6 +412,14 @@ def main():
                         "peak": peak, "unit": "TFLOP/s", "frac": round(issued / peak, 4),
                         "algorithmic_tflops": round(achieved, 2),
                         "traffic": pmc_traffic(VARIANTS[v], same_job), "launches": int(cnt), "avg_launch_ms": round(ms / cnt, 4),
+                        # every GEMM variant of the timed steps (the dominant one above is simply the largest by summed
+                        # time; TN and NN are within 1 % of each other at the headline shape, so which one leads varies)
+                        "variants": {VARIANTS[i]: {"launches": int(prof_out[i * 3]),
+                                                   "ms_per_step": round(prof_out[i * 3 + 1] / args.steps, 3),
+                                                   "tflops": round(prof_out[i * 3 + 2] / (prof_out[i * 3 + 1] * 1e-3) / 1e12, 2),
+                                                   "frac_of_fp32_mfma_peak": round(prof_out[i * 3 + 2] / (prof_out[i * 3 + 1] * 1e-3) / 1e12
+                                                                                   / PEAK_FP32_MFMA_TFLOPS, 4)}
+                                     for i in range(6) if prof_out[i * 3] > 0},
                         "gemm_share_of_step": round(tot_ms / args.steps / ms_per_step, 4),
                         "all_gemm_tflops": round(sum(prof_out[i * 3 + 2] for i in range(7)) / (tot_ms * 1e-3) / 1e12, 2)}
         return {"value": round(tokens_per_step * args.steps / elapsed, 1), "ms_per_step": round(ms_per_step, 3),

@@ -892,10 +892,13 @@ class ProjNLLFunction(torch.autograd.Function):
         if with_grad:
             ctx.save_for_backward(dh, dW, db)
         ctx.mark_non_differentiable(tok)
+        ctx.set_materialize_grads(False)          # tok's (never defined) gradient arrives as None, not as an [N] zero fill
         return loss, tok
 
     @staticmethod
     def backward(ctx, dloss, _dtok):
+        if dloss is None:
+            return None, None, None, None, None, None, None
         _single_use(ctx, "ProjNLLFunction")
         dh, dW, db = ctx.saved_tensors
         g = _f32c(dloss).reshape(1)
