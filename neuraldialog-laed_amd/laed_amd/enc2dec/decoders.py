@@ -139,9 +139,10 @@ class DecoderRNN(BaseRNN):
             (the reference never gathers decoder_hidden) -- reproduced, not fixed;
           * after max_length steps the best final slot is traced back through the back pointers to the 1-best sequence;
           * `length` has one entry per (sequence, slot): first step at which that slot emitted EOS.
-        Parity is UNPINNED: the reference's own back-tracking does not run under Python 3 / torch >= 0.4
-        (`torch.cat` of 0-d tensors, true division in `top_id.div`), so this is checked against the oracle's restatement
-        only (oracle.decoder_beam).  Per step: embedding gather, GRU cell, projection and log-softmax on the HIP
+        The search loop is pinned by tests/golden/beam.npz (the reference's loop runs under torch 2: its per-step fed
+        symbols and log-probs were recorded; `ret_dict['beam_symbols']` [L,B,beam] exposes ours); the back-tracking is
+        PARITY UNPINNED -- the reference's own dies there (`torch.cat` of 0-d tensors, true division in `top_id.div`) --
+        and is checked against the oracle's restatement (oracle.decoder_beam).  Per step: embedding gather, GRU cell, projection and log-softmax on the HIP
         kernels; candidate ranking is torch.topk on the device (selection, GEN-side only)."""
         B, K, V, L = batch_size, int(beam_size), self.output_size, self.max_length
         with torch.no_grad():
@@ -182,7 +183,8 @@ class DecoderRNN(BaseRNN):
             final[:, di] = all_sym[di][rows, best]
             best = all_bp[di][rows, best]
         seq = torch.from_numpy(final).to(dev)
-        ret_dict = {DecoderRNN.KEY_SEQUENCE: [seq[:, t:t + 1] for t in range(L)], DecoderRNN.KEY_LENGTH: lengths.tolist()}
+        ret_dict = {DecoderRNN.KEY_SEQUENCE: [seq[:, t:t + 1] for t in range(L)], DecoderRNN.KEY_LENGTH: lengths.tolist(),
+                    'beam_symbols': all_sym}
         decoder_outputs = LazyLogProbs(torch.stack(hiddens), self.project, B * K)
         return decoder_outputs, h.unsqueeze(0), ret_dict
 

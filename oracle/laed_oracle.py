@@ -183,22 +183,25 @@ def decoder_sample(P, prefix, emb_w, h0, max_len, go_id, eos_id, u):
     return torch.cat(seq, dim=1), lengths.tolist(), h
 
 
-def decoder_beam(P, prefix, emb_w, h0, max_len, go_id, eos_id, beam_size):
+def decoder_beam(P, prefix, emb_w, h0, max_len, go_id, eos_id, beam_size, trace=False):
     """DecoderRNN GEN with gen_type='beam', laed/enc2dec/decoders.py:194-202,222-235,270-291, restated with the integer
-    semantics of the torch the reference targets (top_id.div = floor division).  PARITY UNPINNED: the reference's own
-    back-tracking does not run under Python 3 / torch 2 (torch.cat of 0-d tensors at :289), so no golden vector exists.
-    As in the reference the hidden states are NOT reordered by the back pointers.
-    Returns (sequence [B,max_len] int64, lengths list of B*beam)."""
+    semantics of the torch the reference targets (top_id.div = floor division).  As in the reference the hidden states
+    are NOT reordered by the back pointers.  The search LOOP is pinned by tests/golden/beam.npz (the reference's own loop
+    runs under torch 2 and its per-step fed symbols and log-probs were recorded: make_goldens_beam.py); the
+    back-tracking after it is PARITY UNPINNED -- the reference's dies at :289 (torch.cat of 0-d tensors).
+    Returns (sequence [B,max_len] int64, lengths list of B*beam); with trace=True also (per-step symbols [L,B,K], per-step
+    log-probs [L,B*K,V])."""
     B, K = h0.shape[0], beam_size
     h = h0.repeat(1, K).view(B * K, -1)                                  # repeat_state, base_modules.py:69-71
     ids = torch.full((B * K, 1), go_id, dtype=torch.int64)
     V = P[prefix + 'project.weight'].shape[0]
     cum_sum = None
-    syms, bps = [], []
+    syms, bps, lps = [], [], []
     lengths = np.array([max_len] * (B * K))
     for di in range(max_len):
         lp, h = decoder_teacher(P, prefix, emb_w, ids, h)
         step = lp[:, 0]
+        lps.append(step)
         if di == 0:
             seq_score = step.reshape(B, -1)[:, :V]
         else:
@@ -216,6 +219,8 @@ def decoder_beam(P, prefix, emb_w, h0, max_len, go_id, eos_id, beam_size):
     for di in range(max_len - 1, -1, -1):
         out[:, di] = syms[di][rows, best]
         best = bps[di][rows, best]
+    if trace:
+        return out, lengths.tolist(), torch.stack(syms), torch.stack(lps)
     return out, lengths.tolist()
 
 

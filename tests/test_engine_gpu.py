@@ -233,3 +233,28 @@ def test_beam_search_vs_oracle_restatement():
         if beam == 1:
             _, _, g = dec(B, None, h0.cuda(), mode=GEN, gen_type='greedy')
             assert np.array_equal(seq, torch.cat(g[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_beam_search_loop_vs_reference_trajectory(tag):
+    """DecoderRNN(gen_type='beam') on the HIP kernels against the trajectory of the REFERENCE's own beam-search loop
+    (tests/golden/beam.npz: per-step fed symbols recorded while the reference ran; its back-tracking does not run): the
+    symbols chosen at every step exact (every ranking of the golden has a gap > 1e-3 between the last kept and the first
+    dropped candidate), and the back-tracked 1-best equal to the oracle's restatement."""
+    from helpers import load_golden
+    from laed_amd.enc2dec.decoders import GEN, DecoderRNN
+    from oracle import laed_oracle as O
+    G = load_golden("beam")
+    V, L, E, H, B, K = (int(x) for x in G[tag + "/dims"])
+    dec = DecoderRNN(V, L, E, H, 2, 3, n_layers=1, rnn_cell='gru', use_gpu=True)
+    sd = {k[len(tag) + 4:]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith(tag + "/sd/")}
+    dec.load_state_dict(sd)
+    dec.cuda().eval()
+    h0 = torch.from_numpy(np.array(G[tag + "/h0"]))
+    _, _, ret = dec(B, None, h0.cuda(), mode=GEN, gen_type='beam', beam_size=K)
+    fed = G[tag + "/fed"]
+    assert np.array_equal(ret['beam_symbols'].reshape(L, B * K)[:L - 1], fed[1:])
+    P = {"d." + k: v for k, v in sd.items()}
+    ref_seq, ref_len = O.decoder_beam(P, "d.", P["d.embedding.weight"], h0[0], L, 2, 3, K)
+    seq = torch.cat(ret[DecoderRNN.KEY_SEQUENCE], dim=1).cpu().numpy()
+    assert np.array_equal(seq, ref_seq.numpy()) and list(ret[DecoderRNN.KEY_LENGTH]) == list(ref_len)

@@ -247,3 +247,24 @@ def test_oracle_beam_search_degenerates_to_greedy_and_tracks_back():
     lp0, _ = O.decoder_teacher(P, "d.", P["d.embedding.weight"], torch.full((5, 1), 2, dtype=torch.int64), h0)
     top3 = lp0[:, 0].topk(3)[1]
     assert all(int(s3[b, 0]) in top3[b].tolist() for b in range(5))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_beam_search_loop_vs_reference_trajectory(tag):
+    """oracle.decoder_beam against the trajectory of the REFERENCE's own beam-search loop (tests/golden/beam.npz,
+    make_goldens_beam.py: the loop of decoders.py:258-268 runs under torch 2, only the back-tracking after it dies): the
+    symbols fed back at every step exact, the per-step log-probs -- which carry the reference's quirk of NOT reordering
+    hidden states by the back pointers -- to 1e-5."""
+    from helpers import load_golden
+    G = load_golden("beam")
+    V, L, E, H, B, K = (int(x) for x in G[tag + "/dims"])
+    assert float(G[tag + "/gap"].min()) > 1e-3 and "cannot be concat" in str(G[tag + "/died"])
+    P = {"d." + k[len(tag) + 4:]: torch.from_numpy(np.array(G[k])) for k in G.files if k.startswith(tag + "/sd/")}
+    h0 = torch.from_numpy(np.array(G[tag + "/h0"]))[0]
+    with torch.no_grad():
+        seq, lengths, syms, lps = O.decoder_beam(P, "d.", P["d.embedding.weight"], h0, L, 2, 3, K, trace=True)
+    fed = G[tag + "/fed"]
+    assert (fed[0] == 2).all()                                              # step 0 feeds <s> to every slot
+    assert np.array_equal(syms.numpy().reshape(L, B * K)[:L - 1], fed[1:])
+    assert np.max(np.abs(lps.numpy() - G[tag + "/logp"])) < 1e-5
+    assert seq.shape == (B, L) and len(lengths) == B * K
