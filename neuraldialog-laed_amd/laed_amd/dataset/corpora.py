@@ -11,9 +11,10 @@ Rules kept from the reference (file:line there):
     config.include_eod is set and true;
   * vocabulary (:82-104,160-180,264-285): words of the TRAIN split by descending count, cut at max_vocab_cnt, after
     [<pad>, <unk>] (PTB) or [<pad>, <unk>, <sys>, <usr>] (dialog corpora); unknown words map to <unk>.
-Parity: UNPINNED against the reference (its readers need Python 2 and nltk and do not run in the build container;
-count ties are ordered by first occurrence here, by dict order there).  tests/test_dataset_cpu.py checks the rules
-above on small synthetic files in the three formats.
+Parity: tests/golden/corpora.npz records what the reference's reader methods, run unmodified under Python 3
+(tests/golden/make_goldens_corpora.py; count ties come out in first-occurrence order there as here), made of real
+Stanford / DailyDialog text and PTB-format lines; tests/test_dataset_cpu.py holds these readers to it id for id.  The
+tokeniser's regex engine is `re` on both sides (nltk absent): the pattern is the reference's, the matching is restated.
 """
 import json
 import os

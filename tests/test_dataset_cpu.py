@@ -1,5 +1,6 @@
 """Data layer (laed_amd/dataset): loaders against batches produced by RUNNING the reference loaders
-(tests/golden/make_goldens_loaders.py), corpus readers against their documented rules on synthetic files, and a
+(tests/golden/make_goldens_loaders.py), corpus readers against what the reference's reader methods made of the same
+text (tests/golden/make_goldens_corpora.py) and against their documented rules on synthetic files, and a
 real-text pass over the DailyDialog / Stanford splits that ship with the reference when that tree is present
 (build container only; skipped elsewhere).  CPU only, no kernels."""
 import json
@@ -159,3 +160,92 @@ def test_real_text_daily_dialog_and_stanford_through_the_loaders(tmp_path):
         assert b.contexts.shape[0] == 30 and b.outputs[:, 1].tolist().count(0) == 0
         assert set(np.unique(b.outputs[:, 1])) <= {c.rev_vocab['<sys>'], c.rev_vocab['<usr>'], c.rev_vocab['<d>'],
                                                     c.rev_vocab['</d>']}
+
+
+def _flatten(id_split, dialog):
+    dialogs = id_split if dialog else [[t] for t in id_split]
+    ids = [i for d in dialogs for t in d for i in t.utt]
+    ulen = [len(t.utt) for d in dialogs for t in d]
+    spk = [str(t.speaker) for d in dialogs for t in d]
+    meta = ["" if t.get('meta') is None else "%s/%s" % (t.meta['act'], t.meta['emotion']) for d in dialogs for t in d]
+    return ids, ulen, [len(d) for d in dialogs], spk, meta
+
+
+def _check_against_record(G, name, c, dialog):
+    assert c.vocab == G[name + "/vocab"].tolist(), name
+    assert c.unk_id == int(G[name + "/unk_id"])
+    assert [c.rev_vocab[t] for t in c.vocab[:4]] == G[name + "/rev_vocab_of_specials"].tolist()
+    ids = c.get_corpus()
+    for split in ("train", "valid", "test"):
+        got = _flatten(ids[split], dialog)
+        for k, v in zip(("ids", "utt_lens", "dialog_lens", "speakers", "metas"), got):
+            assert list(v) == G["%s/%s/%s" % (name, split, k)].tolist(), (name, split, k)
+
+
+def test_corpus_readers_reproduce_what_the_reference_readers_made():
+    """tests/golden/corpora.npz holds what the REFERENCE's reader methods (corpora.py:53-126, :149-198, :229-307, run
+    unmodified by tests/golden/make_goldens_corpora.py) made of real Stanford / DailyDialog text that ships with the
+    reference and of PTB-format lines: token lists -> count-ordered, cut vocabulary (with the doubled <sys>/<usr> slots)
+    -> id corpora, speakers and act / emotion metas.  This repo's readers must give the same, id for id.  The tokeniser's
+    pattern was the reference's, its engine `re` standing in for nltk (absent): that one step is restated on both sides."""
+    from laed_amd.dataset import corpora
+    G = load_golden("corpora")
+    for name in ("stanford", "stanford_noeod_fullvocab"):
+        inputs = json.loads(str(G[name + "/inputs_json"]))
+        c = corpora.StanfordCorpus.__new__(corpora.StanfordCorpus)
+        c.config = Namespace(include_eod=True) if bool(G[name + "/include_eod"]) else Namespace()
+        c.tokenize = corpora.get_chat_tokenize()
+        c.train_corpus, c.valid_corpus, c.test_corpus = (c._process_dialog(inputs[s]) for s in ("train", "valid", "test"))
+        c._build_vocab(int(G[name + "/max_vocab_cnt"]))
+        _check_against_record(G, name, c, True)
+    for name in ("daily_dialog", "daily_dialog_noeod_fullvocab"):
+        assert int(G[name + "/non_ascii_bytes_in_inputs"]) > 0          # the ascii-ignore step has something to drop
+        c = corpora.DailyDialogCorpus.__new__(corpora.DailyDialogCorpus)
+        eod = int(G[name + "/include_eod"])
+        c.config = Namespace() if eod < 0 else Namespace(include_eod=bool(eod))
+        c.tokenize = corpora.get_chat_tokenize()
+        for s in ("train", "valid", "test"):
+            txt, act, emo = (G["%s/inputs/%s/%s" % (name, s, k)].tobytes().splitlines(True) for k in ("txt", "act", "emo"))
+            setattr(c, s + "_corpus", c._process_dialog(zip(txt, act, emo)))
+        c._build_vocab(int(G[name + "/max_vocab_cnt"]))
+        _check_against_record(G, name, c, True)
+    inputs = json.loads(str(G["ptb/inputs_json"]))
+    c = corpora.PTBCorpus.__new__(corpora.PTBCorpus)
+    c.config = Namespace()
+    c.tokenize = corpora.get_chat_tokenize()
+    c.train_corpus, c.valid_corpus, c.test_corpus = (c._process_data(inputs[s]) for s in ("train", "valid", "test"))
+    c._build_vocab(int(G["ptb/max_vocab_cnt"]))
+    _check_against_record(G, "ptb", c, False)
+    tok = corpora.get_chat_tokenize()
+    assert [tok(p) for p in G["tokenize/probes"].tolist()] == json.loads(str(G["tokenize/tokens_json"]))
+
+
+def test_corpus_readers_from_files_equal_the_method_path(tmp_path):
+    """The constructors (file reading: 'rb' lines for DailyDialog, utf-8 JSON for Stanford, text lines for PTB) give the
+    same corpora as the method path the record above pins, on the same inputs written back to files."""
+    from laed_amd.dataset import corpora
+    G = load_golden("corpora")
+    dd = tmp_path / "dd"
+    for split, s in (("train", "train"), ("validation", "valid"), ("test", "test")):
+        (dd / split).mkdir(parents=True)
+        for fname, k in (("dialogues.txt", "txt"), ("dialogues_act.txt", "act"), ("dialogues_emotion.txt", "emo")):
+            (dd / split / fname).write_bytes(G["daily_dialog/inputs/%s/%s" % (s, k)].tobytes())
+    c = corpora.DailyDialogCorpus(Namespace(data_dir=[str(dd)], max_utt_len=40,
+                                            max_vocab_cnt=int(G["daily_dialog/max_vocab_cnt"])))
+    _check_against_record(G, "daily_dialog", c, True)
+    st = tmp_path / "st"
+    st.mkdir()
+    inputs = json.loads(str(G["stanford/inputs_json"]))
+    for fname, s in (("kvret_train_public.json", "train"), ("kvret_dev_public.json", "valid"),
+                     ("kvret_test_public.json", "test")):
+        (st / fname).write_text(json.dumps(inputs[s]), encoding="utf-8")
+    c = corpora.StanfordCorpus(Namespace(data_dir=[str(st)], max_utt_len=40, include_eod=True,
+                                         max_vocab_cnt=int(G["stanford/max_vocab_cnt"])))
+    _check_against_record(G, "stanford", c, True)
+    ptb = tmp_path / "ptb"
+    ptb.mkdir()
+    inputs = json.loads(str(G["ptb/inputs_json"]))
+    for s in ("train", "valid", "test"):
+        (ptb / ("ptb.%s.txt" % s)).write_text("".join(inputs[s]), encoding="utf-8")
+    c = corpora.PTBCorpus(Namespace(data_dir=[str(ptb)], max_utt_len=40, max_vocab_cnt=int(G["ptb/max_vocab_cnt"])))
+    _check_against_record(G, "ptb", c, False)
