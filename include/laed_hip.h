@@ -376,6 +376,9 @@ int laed_dot(const float* a, const float* b, int64_t n, float* out, void* stream
 int laed_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream);   /* y = a*x + b*y */
 int laed_scale_by_dev(float* y, const float* x, const float* s, int64_t n, void* stream); /* y = s[0]*x */
 int laed_scale_by_dev_multi(int ntensors, float* const* y, const int64_t* n, const float* s, void* stream); /* y_t *= s[0], <= 8 tensors, one launch */
+/* sig[i] = sigmoid(x[i]), tnh[i] = tanh(x[i]) with the branch-free gate functions every GRU kernel of the library applies
+ * (torch.sigmoid / torch.tanh inside nn.GRU, base_modules.py:43-45): exposed so that their accuracy can be checked on its own */
+int laed_gate_functions(const float* x, int64_t n, float* sig, float* tnh, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): when enabled, every GEMM launch is bracketed by HIP events

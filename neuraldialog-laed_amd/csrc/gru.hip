@@ -11,9 +11,18 @@
 // Time-major storage makes h_{t-1} for all (t,b) one plain matrix: hbuf[0 : T*B] (hbuf[0] = h0).
 #include "laed_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
+
+// uniform base pointer + 32-bit BYTE offset per lane (the form the hardware addresses with a scalar base register)
+__device__ __forceinline__ float ldb(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stb(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 
 struct GruStepArgs {
     const float* hprev;   // [B][H]
@@ -24,6 +33,7 @@ struct GruStepArgs {
     float* hn;            // [B][H] or NULL
     int B, H;
     int units_in_x;       // grid = (unit tiles, row tiles) instead of (row tiles, unit tiles)
+    int narrow;           // B * 3H < 2^30: the gate epilogue may address with 32-bit element offsets
 };
 
 // WM row tiles x WK K-splits = NT/64 waves (4 waves with K tiles of 32, or 8 waves with K tiles of 64: in both a load
@@ -68,14 +78,44 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     constexpr int EPW = 16 / EW;
     float pre[EPW][4];
     float bhr = 0.f, bhz = 0.f, bhn = 0.f;
+    // interior blocks (whole tile inside [B] x [H], 16-byte aligned operands): no guards anywhere, 32-bit element offsets
+    // from the uniform base pointers (one VALU add per access instead of a 64-bit add pair)
+    const bool interior = VEC && (m0 + BR <= B) && (j0 + UB <= H);
+    const bool lean = interior && p.narrow;
+    const int jj = j0 + wu * 32 + (tid & 31);
+    // lane's first row: accumulator element e of a 32x32 tile is row (e & 3) + 8 (e >> 2) + 4 (lane >> 5); with two
+    // epilogue waves wave wq owns e in [8 wq, 8 wq + 8), i.e. 16 wq rows further down
+    const int row0 = m0 + wm * 32 + 4 * ((tid & 63) >> 5) + (EW == 2 ? 16 * wq : 0);
+    // lean blocks address the gate operands as uniform base + 32-bit byte offset
+    const unsigned og = 4u * ((unsigned)row0 * 3u * (unsigned)H + (unsigned)jj), oh = 4u * ((unsigned)row0 * (unsigned)H + (unsigned)jj);
+    const unsigned hb = 4u * (unsigned)H;              // bytes per row of [.][H]
+    auto pre_load = [&](int i) {                       // i = 4 ee + k, a compile-time constant wherever it is called
+        const int ee = i >> 2, k = i & 3;
+        const unsigned dr = (ee & 3) + 8 * (ee >> 2);
+#if defined(GRU_EXP) && (GRU_EXP & 16)
+        pre[ee][k] = bhr;
+#else
+        pre[ee][k] = k < 3 ? ldb(p.gates, og + dr * 3u * hb + k * hb) : ldb(p.hprev, oh + dr * hb);
+#endif
+    };
+    // The 4 EPW gate operands per lane are 67 MB per step at B = 4096 -- a third of what the step moves.  Issued first
+    // thing (as they were until round 3) they sit in front of the first K tiles in every wave's in-order load queue and
+    // the K loop starts late in each round of blocks (ablation: 224 -> 212 us per step without them); blocks that run the
+    // scheduled loop therefore issue them BEHIND the loads of K tiles 0 and 1, so that tile 0 multiplies while they land.
+    const int nfull = H / BK;
+    const bool late = lean && nfull >= 2;
     if (wq < EW) {
-        const int jj = j0 + wu * 32 + (tid & 31);
-        if (jj < H) {
+        if (lean) {
+            bhr = p.b_hh[jj]; bhz = p.b_hh[H + jj]; bhn = p.b_hh[2 * H + jj];
+            if (!late) {
+#pragma unroll
+                for (int i = 0; i < 4 * EPW; ++i) pre_load(i);
+            }
+        } else if (jj < H) {
             bhr = p.b_hh[jj]; bhz = p.b_hh[H + jj]; bhn = p.b_hh[2 * H + jj];
 #pragma unroll
             for (int ee = 0; ee < EPW; ++ee) {
-                const int e = wq * EPW + ee;
-                const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * ((tid & 63) >> 5);
+                const int row = row0 + (ee & 3) + 8 * (ee >> 2);
                 if (row < B) {
                     const float* g = p.gates + (int64_t)row * 3 * H;
                     pre[ee][0] = g[jj]; pre[ee][1] = g[H + jj]; pre[ee][2] = g[2 * H + jj];
@@ -140,8 +180,6 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
     const int nkt = (H + BK - 1) / BK;
     const int lrow = lane & 31, lk = lane >> 5;
     // interior blocks: scheduled loop (see sgemm.hip) -- loads / LDS reads / LDS stores sit in the MFMA issue gaps
-    const bool interior = VEC && (m0 + BR <= B) && (j0 + UB <= H);
-    const int nfull = H / BK;
     const bool fast = interior && nfull > 0;
     constexpr int KS = BK / 2 / WK;            // k pairs per wave per K tile
     constexpr int Q = 3 * KS;                  // MFMA issue gaps per K tile
@@ -185,6 +223,10 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         gw += BK;
 #pragma unroll
         for (int u = 0; u < NL; ++u) load_unit(u);
+        if (late && wq < EW) {
+#pragma unroll
+            for (int i = 0; i < 4 * EPW; ++i) pre_load(i);
+        }
         for (; kt + 1 < nfull; ++kt) {
             const float* h_s = sH + cur * BK * SH + wm * 32 + lrow + (2 * wq + lk) * SH;
             const float* w_s = sW + cur * BK * SW + wu * 32 + lrow + (2 * wq + lk) * SW;
@@ -239,6 +281,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
             laed_mfma_32x32x2(acc[1], a, b1);
             laed_mfma_32x32x2(acc[2], a, b2);
         }
+        laed_mfma_drain(acc);                       // inside the body, every pass: see the generic loop of sgemm.hip
         if (more) store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -267,27 +310,60 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
         }
     }
 
-    const int j = j0 + wu * 32 + lrow;
-    if (j >= H) return;
+    // gate epilogue on the wave's EPW accumulator rows starting at element E0 (compile-time: the accumulators are registers)
+    auto gates_of = [&](auto e0c, auto keepc) {
+        constexpr int E0 = decltype(e0c)::value;
+        constexpr bool KEEP = decltype(keepc)::value;      // training: r, z, n and gh_n are kept for backward
+        if (lean) {
+#if defined(GRU_EXP) && (GRU_EXP & 8)
+            float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        if (e / EPW != wq) continue;             // compile-time e, wave-uniform wq
-        const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        if (row < B) {
-            float* g = p.gates + (int64_t)row * 3 * H;
-            const int ee = e % EPW;
-            const float ghn = acc[2][e] + bhn;
-            const float r = sigmoidf_acc(pre[ee][0] + acc[0][e] + bhr);
-            const float z = sigmoidf_acc(pre[ee][1] + acc[1][e] + bhz);
-            const float n = tanhf(pre[ee][2] + r * ghn);
-            const float hp = pre[ee][3];
-            p.hout[(int64_t)row * H + j] = (1.0f - z) * n + z * hp;
-            if (p.hn != nullptr) {
-                g[j] = r; g[H + j] = z; g[2 * H + j] = n;
-                p.hn[(int64_t)row * H + j] = ghn;
+            for (int ee = 0; ee < EPW; ++ee) sum += acc[0][E0 + ee] + acc[1][E0 + ee] + acc[2][E0 + ee] + pre[ee][0] + pre[ee][1] + pre[ee][2] + pre[ee][3];
+            if (sum == 1234.5f) stb(p.hout, oh, sum + og + hb);
+            return;
+#endif
+#pragma unroll
+            for (int ee = 0; ee < EPW; ++ee) {
+                const int e = E0 + ee;
+                const unsigned dr = (ee & 3) + 8 * (ee >> 2);
+                const float ghn = acc[2][e] + bhn;
+                const float r = sigmoidf_acc(pre[ee][0] + acc[0][e] + bhr);
+                const float z = sigmoidf_acc(pre[ee][1] + acc[1][e] + bhz);
+                const float n = tanhf_gate(pre[ee][2] + r * ghn);
+                const unsigned a = og + dr * 3u * hb, b = oh + dr * hb;
+                stb(p.hout, b, (1.0f - z) * n + z * pre[ee][3]);
+                if (KEEP) {
+                    stb(p.gates, a, r); stb(p.gates, a + hb, z); stb(p.gates, a + 2u * hb, n);
+                    stb(p.hn, b, ghn);
+                }
+            }
+            return;
+        }
+        if (jj >= H) return;
+#pragma unroll
+        for (int ee = 0; ee < EPW; ++ee) {
+            const int e = E0 + ee;
+            const int row = row0 + (ee & 3) + 8 * (ee >> 2);
+            if (row < B) {
+                float* g = p.gates + (int64_t)row * 3 * H;
+                const float ghn = acc[2][e] + bhn;
+                const float r = sigmoidf_acc(pre[ee][0] + acc[0][e] + bhr);
+                const float z = sigmoidf_acc(pre[ee][1] + acc[1][e] + bhz);
+                const float n = tanhf_gate(pre[ee][2] + r * ghn);
+                p.hout[(int64_t)row * H + jj] = (1.0f - z) * n + z * pre[ee][3];
+                if (KEEP) {
+                    g[jj] = r; g[H + jj] = z; g[2 * H + jj] = n;
+                    p.hn[(int64_t)row * H + jj] = ghn;
+                }
             }
         }
-    }
+    };
+    auto gates_at = [&](auto e0c) {
+        if (p.hn != nullptr) gates_of(e0c, std::true_type());
+        else gates_of(e0c, std::false_type());
+    };
+    if (EW == 2 && wq == 1) gates_at(std::integral_constant<int, 16 - EPW>());   // = 8 when EW == 2 (never taken otherwise)
+    else gates_at(std::integral_constant<int, 0>());
 }
 
 template <int WM, int WK, int NT = 256, int BKT = 32, int WU = 1>
@@ -297,20 +373,21 @@ int launch_step(const GruStepArgs& a, bool vec, hipStream_t stream) {
     constexpr int TILE = BKT * (32 * WM + 1 + 96 * WU + 1);
     constexpr int RED = (WK > 1) ? WK * WM * WU * 64 * 48 : 0;
     constexpr size_t lds = sizeof(float) * ((2 * TILE > RED) ? 2 * TILE : RED);
+    auto kern_t = gru_step_fwd_kernel<WM, WK, true, NT, BKT, WU>;
+    auto kern_f = gru_step_fwd_kernel<WM, WK, false, NT, BKT, WU>;
     static uint64_t attr_set = 0;       // per device (and per instantiation: the static lives in the template)
     if (lds > 48 * 1024 && laed_first_use_on_device(&attr_set)) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<WM, WK, true, NT, BKT, WU>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<WM, WK, false, NT, BKT, WU>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess || e2 != hipSuccess) return laed_fail((int)(e1 != hipSuccess ? e1 : e2), "gru_step: hipFuncSetAttribute failed");
     }
     static const int force_x = []() { const char* e = laed_exp_hook("LAED_GRU_UNITS_IN_X"); return e ? atoi(e) : -1; }();
     b.units_in_x = force_x >= 0 ? force_x : 1;
+    b.narrow = ((int64_t)a.B * 3 * a.H < ((int64_t)1 << 30)) ? 1 : 0;
     if (mt > 65535) b.units_in_x = 1;
     dim3 grid = b.units_in_x ? dim3(jt, mt) : dim3(mt, jt);
-    if (vec) hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, true, NT, BKT, WU>), grid, dim3(NT), lds, stream, b);
-    else hipLaunchKernelGGL((gru_step_fwd_kernel<WM, WK, false, NT, BKT, WU>), grid, dim3(NT), lds, stream, b);
+    if (vec) hipLaunchKernelGGL(kern_t, grid, dim3(NT), lds, stream, b);
+    else hipLaunchKernelGGL(kern_f, grid, dim3(NT), lds, stream, b);
     LAED_LAUNCH_CHECK("gru_step_fwd");
     return 0;
 }

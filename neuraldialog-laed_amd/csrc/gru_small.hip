@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTH) void gru_small_fwd_kernel(SmallFwdArgs p) {
         const float ghn = sum_partials<RT, NC>(red, p.nkw, row, 2 * UF + u) + bhn;
         const float r = sigmoidf_acc(gi_r + ghr + bhr);
         const float z = sigmoidf_acc(gi_z + ghz + bhz);
-        const float n = tanhf(gi_n + r * ghn);
+        const float n = tanhf_gate(gi_n + r * ghn);
         h = (1.0f - z) * n + z * hp;
         p.hout[(int64_t)grow * H + j] = h;
         if (p.hn != nullptr) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
                 const float ghn = sum_partials<RT, NC>(red, p.nkw, row, 2 * UF + u) + bhn;
                 const float r = sigmoidf_acc(gi_r + ghr + bhr);
                 const float z = sigmoidf_acc(gi_z + ghz + bhz);
-                const float n = tanhf(gi_n + r * ghn);
+                const float n = tanhf_gate(gi_n + r * ghn);
                 h = (1.0f - z) * n + z * hp;
                 if (dead) h = __builtin_nanf("");         // a timed-out wait poisons the output: loud, not silently stale
                 hp = h;

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/laed_hip.h"
 
@@ -21,6 +23,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void laed_mfma_32x32x2(f32x16& acc, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// The same with accumulator tile I pinned to the physical registers a[16 I : 16 I + 15].  With the plain "a" constraint the
+// register allocator is free to give a tile different registers in different regions of a kernel and to connect them with
+// v_accvgpr_mov copies at the region boundaries -- e.g. on the exit edge of a K loop, straight behind the last MFMA, where
+// the copy reads a tile the matrix core is still writing and no hazard recognizer sees it (the MFMA is inline asm).  This
+// happened in gru_step_fwd_kernel once its K loop had two entry paths (round 3; rows 0 and 27 of every 32-row tile came out
+// wrong).  Pinned tiles leave nothing to copy; tools/check_mfma_hazards.py scans the built library for the pattern.
+template <int I>
+__device__ __forceinline__ void laed_mfma_32x32x2_pin(f32x16& acc, float a, float b) {
+    static_assert(I >= 0 && I < 3, "add a constraint string for this tile");
+    if constexpr (I == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+{a[0:15]}"(acc) : "v"(a), "v"(b));
+    else if constexpr (I == 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+{a[16:31]}"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+{a[32:47]}"(acc) : "v"(a), "v"(b));
+}
+// drain for three pinned tiles (see laed_mfma_drain below)
+__device__ __forceinline__ void laed_mfma_drain_pin3(f32x16 (&acc)[3]) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]));
+}
+
 // The drain carries a DEPENDENCY on every tile it protects: each tile is an in/out operand ("+a") of the drain's asm
 // statements, so any later read of the tile (v_accvgpr_read, extractelement) uses the value the drain "produced" and
 // cannot be scheduled in front of the s_nops -- a memory clobber or `volatile` alone orders memory operations and other
@@ -141,7 +161,38 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, const float* h0, fl
 int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, const float* dhT, float* gates,
                        float* dgh, float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream);
 
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
+template <int... Is, class F>
+__device__ __forceinline__ void laed_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void laed_static_for(F&& f) { laed_static_for_impl(std::make_integer_sequence<int, N>(), f); }
+
+// Gate functions of the GRU kernels: branch-free and short (a recurrence step applies 3 of them per (row, unit), in the
+// epilogue of an MFMA kernel where every VALU instruction is exposed).  v_exp_f32 / v_rcp_f32 are 1-ulp instructions;
+// checked against float64 over [-30, 30] (tests/test_kernels_gpu.py::test_gate_functions): absolute error < 1.2e-7 for
+// both, relative < 4e-7 for tanh everywhere and for sigmoid on |x| <= 4 (its far negative tail carries the rounding of
+// x log2 e: relative |x| 1e-7 on values below 2e-2).  libm's expf / tanhf / IEEE division cost ~140 instructions per (row, unit) with two
+// data-dependent branches; these cost ~35.
+__device__ __forceinline__ float sigmoidf_acc(float x) {
+    // 1 / (1 + 2^(-x log2 e)): 2^(+big) = inf -> 0, 2^(-big) = 0 -> 1, NaN propagates
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float tanhf_gate(float x) {
+    const float ax = fabsf(x);
+    // |x| >= 0.625: 1 - 2 / (e^{2|x|} + 1)
+    const float t = __builtin_amdgcn_exp2f(ax * 2.88539008177792681f);
+    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+    // |x| < 0.625: x + x^3 P(x^2), P fitted to (tanh(x) / x - 1) / x^2 on [0, 0.625] (relative error 8e-8 in fp32)
+    const float s = ax * ax;
+    float p = fmaf(s, -0.005704042501747608f, 0.020637862384319305f);
+    p = fmaf(s, p, -0.05373915657401085f);
+    p = fmaf(s, p, 0.133314311504364f);
+    p = fmaf(s, p, -0.3333328068256378f);
+    const float small = fmaf(ax * s, p, ax);
+    return copysignf(ax < 0.625f ? small : big, x);
+}
 
 // Lane exchange for a butterfly reduction over the 32 lanes that share lane>>5, stage `o` = 1, 2, 4, 8, 16: the partner of
 // __shfl_xor(v, o), but by DPP (a VALU modifier: no LDS crossbar round trip, no lgkmcnt wait) for the four stages inside a

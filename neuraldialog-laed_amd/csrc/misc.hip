@@ -204,6 +204,24 @@ extern "C" int laed_scale_by_dev_multi(int ntensors, float* const* y, const int6
     return 0;
 }
 
+__global__ __launch_bounds__(256) void gate_functions_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ sig,
+                                                             float* __restrict__ tnh) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        sig[i] = sigmoidf_acc(v);
+        tnh[i] = tanhf_gate(v);
+    }
+}
+
+extern "C" int laed_gate_functions(const float* x, int64_t n, float* sig, float* tnh, void* stream) {
+    LAED_CHECK_ARG(n >= 0, "gate_functions: bad size");
+    if (n == 0) return 0;
+    LAED_CHECK_ARG(x && sig && tnh, "gate_functions: null pointer");
+    hipLaunchKernelGGL(gate_functions_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, sig, tnh);
+    LAED_LAUNCH_CHECK("gate_functions");
+    return 0;
+}
+
 extern "C" int laed_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream) {
     LAED_CHECK_ARG(n >= 0, "axpby: bad size");
     if (n == 0) return 0;

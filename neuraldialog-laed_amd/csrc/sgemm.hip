@@ -494,6 +494,11 @@ __device__ __forceinline__ void sgemm_block(const SgemmArgs& p) {
                 for (int j = 0; j < TN; ++j)
                     laed_mfma_32x32x2(acc[i][j], a[i], b[j]);
         }
+        // Drained INSIDE the body, every pass (this loop is not the hot one): behind the loop's exit the register allocator may
+        // move a tile (v_accvgpr_mov / read on the exit edge, straight behind an MFMA it cannot see -- the MFMA is inline asm,
+        // and a drain placed after the loop comes too late for such a copy).  tools/check_mfma_hazards.py found exactly that in
+        // the unaligned-operand instantiations (round 3) and checks every build for it.
+        laed_mfma_drain(acc);
         if (more) {
             add_colsum();
             tile_store<AK, BM, NT, BK>(sA + (cur ^ 1) * BK * SA, tid, ra);

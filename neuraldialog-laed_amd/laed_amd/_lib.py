@@ -83,6 +83,7 @@ _SIGS = {
     "laed_axpby": ([_p, _p, _i64, _f, _f, _p], _i),
     "laed_scale_by_dev": ([_p, _p, _p, _i64, _p], _i),
     "laed_scale_by_dev_multi": ([_i, _p, _p, _p, _p], _i),
+    "laed_gate_functions": ([_p, _i64, _p, _p, _p], _i),
     "laed_prof_enable": ([_i], _i),
     "laed_prof_reserve": ([_i], _i),
     "laed_prof_collect": ([ctypes.POINTER(ctypes.c_double)], _i),

@@ -212,6 +212,36 @@ def test_gru_all_tile_configs(ops, O):
         os.environ.pop("LAED_GRU_WM", None)
 
 
+def test_gate_functions(ops):
+    """The branch-free sigmoid / tanh every GRU kernel applies (laed_common.h), against float64 over the whole range a
+    gate pre-activation can take, including the switch of the tanh form at |x| = 0.625, large arguments and zeros."""
+    from laed_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.linspace(-30, 30, 200001), torch.linspace(-0.7, 0.7, 100001), (torch.rand(100000, generator=g) - 0.5) * 1e-3,
+                   torch.tensor([0.0, -0.0, 0.625, -0.625, 88.0, -88.0, 1e4, -1e4, 1e-30, float("inf"), float("-inf")])])
+    xd = x.cuda()
+    sig, tnh = torch.empty_like(xd), torch.empty_like(xd)
+    check(lib.laed_gate_functions(ptr(xd), xd.numel(), ptr(sig), ptr(tnh), stream()), "gate_functions")
+    x64 = x.double()
+    rs, rt = torch.sigmoid(x64), torch.tanh(x64)
+    ea = (sig.cpu().double() - rs).abs()
+    assert float(ea.max()) < 1.2e-7, float(ea.max())                    # absolute: what a gate value needs
+    es = ea / rs.clamp_min(1e-30)
+    assert float(es[x.abs() <= 4].max()) < 4e-7, float(es[x.abs() <= 4].max())
+    # far tails: the rounding of x * log2(e) is an absolute error of |x| * 4e-8 in the exponent, i.e. a RELATIVE error that
+    # grows with |x| on values that are themselves below 2e-2 (sigmoid(-30) = 9e-14 is off by 2e-6 of itself)
+    far = (x > -80) & (x.abs() > 4)
+    assert float((es[far] / x64.abs()[far]).max()) < 1e-7
+    nz = x64.abs() > 0
+    et = (tnh.cpu().double() - rt).abs()[nz] / rt.abs()[nz]
+    assert float(et.max()) < 4e-7, float(et.max())
+    assert torch.equal(tnh.cpu()[x == 0], x[x == 0]) and bool((torch.signbit(tnh.cpu()) == torch.signbit(x)).all())
+    assert float(tnh.cpu()[-2]) == 1.0 and float(tnh.cpu()[-1]) == -1.0 and float(sig.cpu()[-2]) == 1.0 and float(sig.cpu()[-1]) == 0.0
+    nan = torch.full((4,), float("nan")).cuda()
+    check(lib.laed_gate_functions(ptr(nan), 4, ptr(sig), ptr(tnh), stream()), "gate_functions")
+    assert bool(torch.isnan(sig[:4]).all()) and bool(torch.isnan(tnh[:4]).all())
+
+
 def test_gumbel_latent(ops, O):
     for (R, k, tau, seed) in ((12, 5, 1.0, 1), (600, 10, 1.0, 2), (77, 20, 0.5, 3), (9, 40, 2.0, 4)):
         logits = rnd(R, k, seed=seed, scale=2.0)

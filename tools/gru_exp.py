@@ -26,11 +26,11 @@ def run(path):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             f()
         e1.record()
         torch.cuda.synchronize()
-        out.append("B=%d %.1f us/step" % (B, e0.elapsed_time(e1) / 5 / T * 1e3))
+        out.append("B=%d %.1f us/step" % (B, e0.elapsed_time(e1) / 20 / T * 1e3))
     print(path.split("/")[-1], " | ".join(out), flush=True)
 
 
