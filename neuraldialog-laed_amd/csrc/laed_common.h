@@ -6,7 +6,6 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <type_traits>
-#include <utility>
 
 #include "../../include/laed_hip.h"
 
@@ -23,24 +22,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void laed_mfma_32x32x2(f32x16& acc, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-// The same with accumulator tile I pinned to the physical registers a[16 I : 16 I + 15].  With the plain "a" constraint the
-// register allocator is free to give a tile different registers in different regions of a kernel and to connect them with
-// v_accvgpr_mov copies at the region boundaries -- e.g. on the exit edge of a K loop, straight behind the last MFMA, where
-// the copy reads a tile the matrix core is still writing and no hazard recognizer sees it (the MFMA is inline asm).  This
-// happened in gru_step_fwd_kernel once its K loop had two entry paths (round 3; rows 0 and 27 of every 32-row tile came out
-// wrong).  Pinned tiles leave nothing to copy; tools/check_mfma_hazards.py scans the built library for the pattern.
-template <int I>
-__device__ __forceinline__ void laed_mfma_32x32x2_pin(f32x16& acc, float a, float b) {
-    static_assert(I >= 0 && I < 3, "add a constraint string for this tile");
-    if constexpr (I == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+{a[0:15]}"(acc) : "v"(a), "v"(b));
-    else if constexpr (I == 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+{a[16:31]}"(acc) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+{a[32:47]}"(acc) : "v"(a), "v"(b));
-}
-// drain for three pinned tiles (see laed_mfma_drain below)
-__device__ __forceinline__ void laed_mfma_drain_pin3(f32x16 (&acc)[3]) {
-    asm volatile("s_nop 15\n\ts_nop 3" : "+{a[0:15]}"(acc[0]), "+{a[16:31]}"(acc[1]), "+{a[32:47]}"(acc[2]));
-}
-
+// What the drain cannot protect: a copy the register allocator itself places behind an MFMA -- e.g. v_accvgpr_mov of a tile on
+// the exit edge of a K loop, in FRONT of a drain that follows the loop (seen twice in round 3: gru_step_fwd_kernel with a
+// two-entry K loop, and the unaligned-operand sgemm instantiations).  Loops that are not hot therefore drain inside their
+// body; tools/check_mfma_hazards.py scans every built library for the pattern (tests/test_isa_cpu.py).
 // The drain carries a DEPENDENCY on every tile it protects: each tile is an in/out operand ("+a") of the drain's asm
 // statements, so any later read of the tile (v_accvgpr_read, extractelement) uses the value the drain "produced" and
 // cannot be scheduled in front of the s_nops -- a memory clobber or `volatile` alone orders memory operations and other
@@ -160,14 +145,6 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, const float* h0, fl
                        int H, float* ws, int cu_budget, hipStream_t stream);
 int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, const float* dout, const float* dhT, float* gates,
                        float* dgh, float* dh0, int T, int B, int H, float* ws, int cu_budget, hipStream_t stream);
-
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
-template <int... Is, class F>
-__device__ __forceinline__ void laed_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>()), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void laed_static_for(F&& f) { laed_static_for_impl(std::make_integer_sequence<int, N>(), f); }
 
 // Gate functions of the GRU kernels: branch-free and short (a recurrence step applies 3 of them per (row, unit), in the
 // epilogue of an MFMA kernel where every VALU instruction is exposed).  v_exp_f32 / v_rcp_f32 are 1-ulp instructions;
