@@ -239,12 +239,59 @@ __global__ __launch_bounds__(NTH) void gru_small_bwd_kernel(SmallBwdArgs p) {
 // h_{t-1} of a workgroup's own units stays in registers.  Needs all H/UF workgroups resident at once (H/UF <= 256).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS4 = 16;             // float4 slots per quad in the LDS slab (12 used: keeps the kq groups on disjoint banks)
+// Arrival counters of the persistent launches.  A group's workgroups used to add to ONE counter: agent-scope atomics on one
+// word are served one after the other (11-13 ns each, MI355X_MICROARCH.md "fanin"), i.e. ~1.5 us of a 4-5 us step for the 128
+// workgroups of H = 512.  The counter is therefore kept in up to MAX_SHARDS shards, each on a 128-byte line of its own:
+// workgroup x adds to shard x % nsh, and the polling wave reads every shard with one load instruction (lane s polls shard s)
+// and goes on when all of them have reached their own targets ("valid forms" row 1: a sharded counter, every shard polled).
+// Layout of `sync` (SYNC_WORDS unsigned, zeroed by the preparation launch): word 1 = timeout flag; shard s of group g at
+// word 32 * (1 + g * MAX_SHARDS + s).
+constexpr int MAX_SHARDS = 8, MAX_PGROUPS = 4;
+constexpr int SYNC_WORDS = 32 * (1 + MAX_PGROUPS * MAX_SHARDS);
 constexpr unsigned SPIN_LIMIT = 1000000;    // ~1-2 s of polling (s_sleep + one L2 round trip each): only a grid that can never become resident gets there
 
 // Sticky per-device count of timed-out waits (besides the per-call sync[1] word): the host reads it with
 // laed_gru_persist_timeouts() whenever it next synchronises anyway (e.g. when it sees a NaN loss), so a poisoned output
 // can be told from an ordinary numerical blow-up.  Written with a vector atomic (agent scope); never reset by kernels.
 __device__ unsigned g_persist_timeouts = 0;
+
+// Publishing a workgroup's slice of the quad-major operand: the 4 lanes of a quad hold the 4 floats of one (quad, row) slot;
+// lane 0 of the quad gathers them (DPP quad broadcasts) and writes ONE 16-byte write-through (sc1) store instead of four
+// 4-byte ones -- an sc1 store is one fabric write whatever its size (MI355X_MICROARCH.md: a dword sc1 store costs ~6x the
+// dwordx4 time per byte), and the step waits for every one of them to be acknowledged before it may signal.
+__device__ __forceinline__ void publish_quad(__amdgpu_buffer_rsrc_t out, int byte_off, float v, bool leader) {
+    const int iv = __float_as_int(v);
+    u32x4 d;
+    d.x = (unsigned)__builtin_amdgcn_mov_dpp(iv, 0x00, 0xF, 0xF, true);      // quad_perm [0,0,0,0]
+    d.y = (unsigned)__builtin_amdgcn_mov_dpp(iv, 0x55, 0xF, 0xF, true);      // [1,1,1,1]
+    d.z = (unsigned)__builtin_amdgcn_mov_dpp(iv, 0xAA, 0xF, 0xF, true);      // [2,2,2,2]
+    d.w = (unsigned)__builtin_amdgcn_mov_dpp(iv, 0xFF, 0xF, 0xF, true);      // [3,3,3,3]
+    if (leader) __builtin_amdgcn_raw_buffer_store_b128(d, out, byte_off, 0, 16);                          // aux 16 = sc1
+}
+
+// Wave 0 of a workgroup waits until every shard of its group's counter has reached (workgroups of that shard) x step.
+// BOUNDED: on timeout the flag word and the sticky device counter are raised and *s_dead set, so the grid always drains.
+__device__ __forceinline__ void persist_wait(unsigned* sync, unsigned* cnt, int nsh, unsigned G, unsigned step, int lane,
+                                             unsigned* s_dead) {
+    const bool poller = lane < nsh;
+    const unsigned mine = G / (unsigned)nsh + ((unsigned)lane < G % (unsigned)nsh ? 1u : 0u);   // workgroups x with x % nsh == lane
+    const unsigned target = mine * step;
+    unsigned* const c = cnt + 32 * (poller ? lane : 0);
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = poller ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (__all(!poller || v >= target)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > SPIN_LIMIT) {
+            if (lane == 0) {
+                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&g_persist_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_dead = 1;
+            }
+            break;
+        }
+    }
+}
 
 template <int RT, int NC, int WS>
 __device__ __forceinline__ void persist_core(__amdgpu_buffer_rsrc_t x, const float* __restrict__ slab, int ngrp, int wave, int lane,
@@ -292,8 +339,8 @@ struct PersistFwdArgs {
     float* hbuf;            // [(T+1)][B][H], hbuf[0] = h0
     float* gates;           // [T][B][3H]
     float* hn;              // [T][B][H] or NULL
-    unsigned* sync;         // [0] arrival counter, [1] timeout flag; zeroed before the launch
-    int T, B, H, nkw;
+    unsigned* sync;         // SYNC_WORDS words: timeout flag + sharded arrival counters; zeroed before the launch
+    int T, B, H, nkw, nsh;
 };
 
 template <int RT>
@@ -321,7 +368,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
     }
     float* const hx0 = p.hx0 + (int64_t)grp * H * BP;
     float* const hx1 = p.hx1 + (int64_t)grp * H * BP;
-    unsigned* const cnt = p.sync + 32 * grp;         // one 128-byte line per group; sync[1] stays the shared timeout flag
+    unsigned* const cnt = p.sync + 32 * (1 + grp * MAX_SHARDS);       // this group's shards, a 128-byte line each
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(hx0, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 0x7fffffff, 0x00020000);
     const unsigned G = gridDim.x;
@@ -334,18 +381,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
         if (mine) { gi_r = g[j]; gi_z = g[H + j]; gi_n = g[2 * H + j]; }
         if (t > 0) {                                 // every workgroup's slice of h_{t-1} must have been published
-            if (tid == 0 && !dead) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)t) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > SPIN_LIMIT) {
-                        __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(&g_persist_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_dead = 1;
-                        break;
-                    }
-                }
-            }
+            if (wave == 0 && !dead) persist_wait(p.sync, cnt, p.nsh, G, (unsigned)t, lane, &s_dead);
             __syncthreads();
             dead = s_dead != 0;
         }
@@ -376,12 +412,12 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
                     p.hn[((int64_t)t * B + grow) * H + j] = ghn;
                 }
             }
-            float* hx_out = (t & 1) ? hx0 : hx1;
-            __hip_atomic_store(hx_out + ((int64_t)(j / 4) * BP + row) * 4 + (j & 3), h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            static_assert(UF == 4, "a workgroup's units are one quad of the operand");
+            publish_quad((t & 1) ? rx0 : rx1, (int)(((int64_t)blockIdx.x * BP + row) * 16), h, u == 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores ...
         __syncthreads();                                           // ... before one lane signals for the workgroup
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(cnt + 32 * (blockIdx.x % p.nsh), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -399,8 +435,8 @@ struct PersistBwdArgs {
     float* gates;            // [T][B][3H] in: r,z,n  out: d(gi)
     float* dgh;              // [T][B][3H] out
     float* dh;               // [B][H] in: dh_T, out: dh_0
-    unsigned* sync;          // [0] arrival counter, [1] timeout flag; zeroed before the launch
-    int T, B, H, nkw;
+    unsigned* sync;          // SYNC_WORDS words: timeout flag + sharded arrival counters; zeroed before the launch
+    int T, B, H, nkw, nsh;
 };
 
 template <int RT>
@@ -423,7 +459,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
     float carry = mine ? p.dh[i] : 0.f;
     float* const dx0 = p.dx0 + (int64_t)grp * K * BP;
     float* const dx1 = p.dx1 + (int64_t)grp * K * BP;
-    unsigned* const cnt = p.sync + 32 * grp;
+    unsigned* const cnt = p.sync + 32 * (1 + grp * MAX_SHARDS);
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(dx0, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(dx1, 0, 0x7fffffff, 0x00020000);
     const unsigned G = gridDim.x;
@@ -443,18 +479,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
             hnv = p.hn[it]; hp = p.hbuf[it];
         }
         if (s > 0) {                                 // every workgroup's slice of dgh_{t+1} must have been published
-            if (tid == 0 && !dead) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G * (unsigned)s) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > SPIN_LIMIT) {
-                        __hip_atomic_store(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(&g_persist_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_dead = 1;
-                        break;
-                    }
-                }
-            }
+            if (wave == 0 && !dead) persist_wait(p.sync, cnt, p.nsh, G, (unsigned)s, lane, &s_dead);
             __syncthreads();
             dead = s_dead != 0;
             if (wave < p.nkw) {
@@ -488,15 +513,17 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
                 d[j] = drp; d[H + j] = dzp; d[2 * H + j] = dnr;
                 carry = dh * z;
             }
-            float* dx_out = (s & 1) ? dx1 : dx0;
-            const int e4 = j & 3;
-            __hip_atomic_store(dx_out + ((int64_t)(j / 4) * BP + row) * 4 + e4, drp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dx_out + ((int64_t)((H + j) / 4) * BP + row) * 4 + e4, dzp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dx_out + ((int64_t)((2 * H + j) / 4) * BP + row) * 4 + e4, dnr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            static_assert(UB % 4 == 0, "a workgroup's units are whole quads of the operand");
+            const __amdgpu_buffer_rsrc_t out = (s & 1) ? rx1 : rx0;
+            const bool lead = (u & 3) == 0;
+            const int q = j / 4;                         // the same for the 4 lanes of a quad (j0 and H are multiples of 4)
+            publish_quad(out, (int)(((int64_t)q * BP + row) * 16), drp, lead);
+            publish_quad(out, (int)(((int64_t)(H / 4 + q) * BP + row) * 16), dzp, lead);
+            publish_quad(out, (int)(((int64_t)(2 * H / 4 + q) * BP + row) * 16), dnr, lead);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(cnt + 32 * (blockIdx.x % p.nsh), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -524,7 +551,8 @@ __global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     }
-    if (sync != nullptr && blockIdx.x == 0 && threadIdx.x < 160) sync[threadIdx.x] = 0u;
+    if (sync != nullptr && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < SYNC_WORDS; i += blockDim.x) sync[i] = 0u;
     constexpr int NC = 3 * UF;
     const int64_t n = (int64_t)(H / UF) * (H / 4) * NC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -545,7 +573,8 @@ __global__ __launch_bounds__(256) void pack_w_bwd_kernel(const float* __restrict
     if (dh0 != nullptr && dh0 != dhT)
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < BH; i += (int64_t)gridDim.x * blockDim.x)
             dh0[i] = dhT != nullptr ? dhT[i] : 0.f;
-    if (sync != nullptr && blockIdx.x == 0 && threadIdx.x < 160) sync[threadIdx.x] = 0u;
+    if (sync != nullptr && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < SYNC_WORDS; i += blockDim.x) sync[i] = 0u;
     const int64_t n = (int64_t)(H / UB) * (3 * H / 4) * UB;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % UB);
@@ -661,6 +690,12 @@ int laed_gru_small_bp(int B) { return B <= 64 ? (B + 15) / 16 * 16 : mid_rows();
 // rows; grouped: DI-VAE step at B = 30 1.99 -> 1.78 ms, DI-VST at B = 60 3.82 -> 3.33 ms, losses bit-identical).
 // LAED_GRU_PGROUPS=0 (hooks build) keeps one group.
 struct PersistGroups { int rows, groups; };
+// shards of a group's arrival counter: 8 (one per XCD's share of the workgroups); LAED_GRU_SHARDS=1..8 (hooks build) for A/B
+static int persist_shards() {
+    static const int n = []() { const char* e = laed_exp_hook("LAED_GRU_SHARDS"); const int v = e ? atoi(e) : MAX_SHARDS;
+                                return v < 1 ? 1 : (v > MAX_SHARDS ? MAX_SHARDS : v); }();
+    return n;
+}
 static PersistGroups persist_groups(int B, int grid_x, int cu_limit) {
     static const bool on = []() { const char* e = laed_exp_hook("LAED_GRU_PGROUPS"); return !(e != nullptr && atoi(e) == 0); }();
     const int bp = laed_gru_small_bp(B);
@@ -676,10 +711,10 @@ static PersistGroups persist_groups(int B, int grid_x, int cu_limit) {
 static int small_ws_rows(int B) { return B <= 64 ? 64 : laed_gru_small_bp(B) * small_groups(B); }
 
 int64_t laed_gru_small_fwd_ws(int B, int H) {
-    return (int64_t)3 * H * H + (int64_t)2 * H * small_ws_rows(B) + 160;
+    return (int64_t)3 * H * H + (int64_t)2 * H * small_ws_rows(B) + SYNC_WORDS;
 }
 int64_t laed_gru_small_bwd_ws(int B, int H) {
-    return (int64_t)3 * H * H + (int64_t)2 * 3 * H * small_ws_rows(B) + 160;
+    return (int64_t)3 * H * H + (int64_t)2 * 3 * H * small_ws_rows(B) + SYNC_WORDS;
 }
 
 // forward over all T steps; gates already holds x W_ih^T + b_ih, hbuf[0] = h0.  ws: laed_gru_small_fwd_ws floats, 16-byte aligned.
@@ -701,9 +736,10 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, const float* h0, fl
         const PersistGroups pg = persist_groups(B, H / UF, cu_limit);
         BP = pg.rows;
         NG = pg.groups;
+        if (NG > MAX_PGROUPS) return laed_fail(LAED_E_SIZE, "gru_small: %d row groups (at most %d)", NG, MAX_PGROUPS);
     }
     float* hx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)H * BP * NG};
-    // a 128-byte line of arrival counters per group (<= 4) + the flag, cleared by the preparation launch
+    // SYNC_WORDS words (flag + sharded arrival counters of <= 4 groups), cleared by the preparation launch
     unsigned* sync = persistent ? reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * H * BP * NG) : nullptr;
     // one preparation launch: pack W_hh, hbuf[0] = h0 (or zeros) + its quad-major image, clear the counters
     hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(256), dim3(256), 0, stream, w_hh, H, wp, h0, hbuf, B, BP, NG, hx[0], sync);
@@ -711,7 +747,7 @@ int laed_gru_small_fwd(const float* w_hh, const float* b_hh, const float* h0, fl
     if (persistent) {
         PersistFwdArgs a;
         a.hx0 = hx[0]; a.hx1 = hx[1]; a.wp = wp; a.b_hh = b_hh; a.hbuf = hbuf; a.gates = gates; a.hn = hn; a.sync = sync;
-        a.T = T; a.B = B; a.H = H; a.nkw = k_waves(H);
+        a.T = T; a.B = B; a.H = H; a.nkw = k_waves(H); a.nsh = persist_shards();
         size_t lds = ((size_t)H * WS4 + (size_t)NW * BP * 3 * UF) * sizeof(float);
         if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU (160 KB LDS per CU)
         if (lds > 160 * 1024) return laed_fail(LAED_E_SIZE, "gru_small: LDS slab too large (H = %d)", H);
@@ -756,11 +792,12 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
     if (persist && NG == 1 && H / UB <= cu_limit) {
         const PersistGroups pg = persist_groups(B, H / UB, cu_limit);
         const int PBP = pg.rows, PG = pg.groups;
+        if (PG > MAX_PGROUPS) return laed_fail(LAED_E_SIZE, "gru_small: %d row groups (at most %d)", PG, MAX_PGROUPS);
         float* pdx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * PBP * PG};
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * PBP * PG);
         PersistBwdArgs a;
         a.dx0 = pdx[0]; a.dx1 = pdx[1]; a.wpT = wpT; a.dout = dout; a.hbuf = hbuf; a.hn = hn; a.gates = gates; a.dgh = dgh;
-        a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H);
+        a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H); a.nsh = persist_shards();
         size_t lds = ((size_t)3 * H * UB + (size_t)NW * PBP * UB) * sizeof(float);
         if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU
         if (lds <= 160 * 1024) {
