@@ -32,6 +32,18 @@ def summary(model, show_weights=True, show_parameters=True):
     return '\n'.join(lines) + '\n) Total Parameters={}'.format(total)
 
 
+_ONES = {}
+
+
+def _one_like(t):
+    """A cached 0-dim constant 1 on t's device (the seed of a backward pass; never written)."""
+    key = (t.device, t.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), device=t.device, dtype=t.dtype)
+    return one
+
+
 class BaseModel(nn.Module):
     def __init__(self, config):
         super(BaseModel, self).__init__()
@@ -52,8 +64,20 @@ class BaseModel(nn.Module):
         raise NotImplementedError
 
     def backward(self, batch_cnt, loss):
+        """model_bases.py:88-90: backward of valid_loss.  Where valid_loss is a plain sum (loss_terms says so) the terms are
+        the roots themselves, each seeded with a cached constant 1: the same gradients, without the add kernel(s) that form
+        the sum and the fill that seeds it -- three to four launches of a 1.5 ms step."""
+        terms = self.loss_terms(loss, batch_cnt)
+        if terms and all(torch.is_tensor(t) and t.is_cuda and t.dim() == 0 and t.requires_grad for t in terms):
+            torch.autograd.backward(terms, [_one_like(t) for t in terms])
+            return
         total_loss = self.valid_loss(loss, batch_cnt)
         total_loss.backward()
+
+    def loss_terms(self, loss, batch_cnt=None):
+        """The tensors whose sum is valid_loss(loss, batch_cnt), or None where valid_loss does more than add (phase
+        switches, weights): backward() then goes through valid_loss itself."""
+        return None
 
     def valid_loss(self, loss, batch_cnt=None):
         total_loss = 0.0

@@ -110,6 +110,9 @@ class DiVAE(_SentBase):
             total_loss = total_loss + loss.reg_kl
         return total_loss
 
+    def loss_terms(self, loss, batch_cnt=None):
+        return [loss.nll] + ([loss.reg_kl] if self.config.use_reg_kl else [])
+
     def forward(self, data_feed, mode, gen_type='greedy', sample_n=1, return_latent=False):
         batch_size = len(data_feed['output_lens'])
         out_utts = self.np2var(data_feed['outputs'], LONG)
@@ -210,15 +213,14 @@ class DiVST(_SentBase):
             # the next decoder's parameters are accumulated on the default stream and produced on the side stream: intended
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
-    def backward(self, batch_cnt, loss):
-        total_loss = self.valid_loss(loss)
-        total_loss.backward()
-
     def valid_loss(self, loss, batch_cnt=None):
         total_loss = loss.prev_nll + loss.next_nll
         if self.config.use_reg_kl:
             total_loss = total_loss + loss.reg_kl
         return total_loss
+
+    def loss_terms(self, loss, batch_cnt=None):
+        return [loss.prev_nll, loss.next_nll] + ([loss.reg_kl] if self.config.use_reg_kl else [])
 
     def forward(self, data_feed, mode, gen_type='greedy', sample_n=1, return_latent=False):
         batch_size = len(data_feed['output_lens'])
