@@ -414,8 +414,22 @@ int gru_step(const GruStepArgs& a, hipStream_t stream) {
     // script: B = 2048 148.5 vs 153.3, B = 4096 293.1 vs 299.6): 1024 blocks are exactly two rounds, where the 2048
     // 64-row blocks run as 2.67 rounds of 3 per CU
     if (cdiv64(a.B, 128) * jt >= 512) return launch_step<4, 1>(a, vec, stream);
-    if (a.B > 32 && cdiv64(a.B, 64) * jt >= 256) return launch_step<2, 2>(a, vec, stream);
-    return launch_step<1, 4>(a, vec, stream);
+    // Below that the launch is one to three rounds of blocks and the rounds decide (round 3, tools/gru_exp.py with
+    // GRU_EXP_B / GRU_EXP_H over B = 128..4096 at H = 256 / 512 / 1024, us per step):
+    //   * at most 256 blocks of 64 rows (one per CU): the 32-row tiles with K split 4 ways run as one or two rounds and beat
+    //     the 64-row / 2-way tiles (H = 1024, B = 512: 36.7 vs 37.9; H = 512, B = 1024: 23.2 vs 24.3; H = 256, B = 2048: 16.7
+    //     vs 17.7); with a long K (H >= 1024) the 8-wave block -- 64 rows, K split 4 ways, 64-deep K tiles, two waves per
+    //     SIMD -- is better still once the 32-row tiles need a second round (B = 384 / 512: 34.1 / 34.5);
+    //   * between 256 and 512 blocks of 64 rows, three rounds of 32-row tiles beat the 64-row tiles, which put two blocks on
+    //     some CUs and one on the rest (H = 1024, B = 640 / 768: 53.3 / 53.9 vs 61.4 / 62.1; H = 512, B = 1536: 33.7 vs 37.6);
+    //   * from 512 blocks of 64 rows (two per CU) those tiles win again (H = 1024, B = 1024: 63.6 vs 68.3).
+    const int64_t n64 = cdiv64(a.B, 64) * jt, n32 = cdiv64(a.B, 32) * jt;
+    if (n64 <= 256) {
+        if (a.H >= 1024 && n32 > 256) return launch_step<2, 4, 512, 64>(a, vec, stream);
+        return launch_step<1, 4>(a, vec, stream);
+    }
+    if (n64 < 512 && n32 <= 768) return launch_step<1, 4>(a, vec, stream);
+    return launch_step<2, 2>(a, vec, stream);
 }
 
 // ---- backward, one timestep: gate gradients (elementwise over [B][H])

@@ -1,13 +1,13 @@
 """Timing-only ablations of the tiled GRU step kernel (-DGRU_EXP=n builds; results are wrong by design for n != 0).
 usage: python tools/gru_exp.py lib.so ..."""
-import ctypes, sys, torch
-H = 1024
+import ctypes, os, sys, torch
+H = int(os.environ.get("GRU_EXP_H", "1024"))
 
 
 def run(path):
     lib = ctypes.CDLL(path)
     out = []
-    for B in (512, 4096):
+    for B in [int(b) for b in os.environ.get("GRU_EXP_B", "512,4096").split(",")]:
         T = 8
         p = ctypes.c_void_p
         hbuf = torch.randn(T + 1, B, H, device="cuda") * 0.1
