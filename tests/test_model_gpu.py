@@ -322,3 +322,28 @@ def test_no_grad_forward_runs_no_backward_kernels(monkeypatch):
     taped = model(feed, mode=TEACH_FORCE)
     assert seen == [True] and all(h is not None for h in hn_args)
     assert close(quiet.nll, float(taped.nll.detach()), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,kind", [("divae_mid", "divae"), ("divst_mid", "divst")])
+def test_backward_rooted_at_the_loss_terms_equals_backward_of_their_sum(name, kind):
+    """BaseModel.backward seeds the loss terms themselves (loss_terms) instead of forming valid_loss and seeding the sum
+    (model_bases.py:88-90): every gradient must come out bit-identical, and loss_terms must add up to valid_loss."""
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    G = load_golden(name)
+    grads = []
+    for rooted in (True, False):
+        model, cfg = build(G, kind, dropout=0.0)
+        model.train()
+        inject_u(model, G["in/u_steps"][0])
+        loss = model(feed_of(G, kind), mode=TEACH_FORCE)
+        terms = model.loss_terms(loss, 0)
+        assert terms is not None and float(sum(terms).detach()) == float(model.valid_loss(loss, 0).detach())
+        if rooted:
+            model.backward(0, loss)
+        else:
+            model.valid_loss(loss, 0).backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 5
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
