@@ -293,9 +293,11 @@ __device__ __forceinline__ void persist_wait(unsigned* sync, unsigned* cnt, int 
     }
 }
 
+// rows: the group's rows that carry data (<= BP).  Lanes of rows beyond it load nothing (their operand is zero): a group of 8
+// rows pulls half the bytes of a 16-row one across the fabric, and that pull is what a step of these kernels waits for.
 template <int RT, int NC, int WS>
 __device__ __forceinline__ void persist_core(__amdgpu_buffer_rsrc_t x, const float* __restrict__ slab, int ngrp, int wave, int lane,
-                                             f32x4 (&acc)[RT]) {
+                                             int rows, f32x4 (&acc)[RT]) {
     constexpr int BP = 16 * RT;
     const int li = lane & 15, kq = lane >> 4;
     const bool bval = li < NC;
@@ -311,7 +313,10 @@ __device__ __forceinline__ void persist_core(__amdgpu_buffer_rsrc_t x, const flo
             const int g = g0 + c;
             if (g < ngrp) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[c][rt] = __builtin_amdgcn_raw_buffer_load_b128(x, aoff + (4 * g * BP + rt * 16) * 16, 0, 16);
+                for (int rt = 0; rt < RT; ++rt) {
+                    a[c][rt] = u32x4{0u, 0u, 0u, 0u};
+                    if (rt * 16 + li < rows) a[c][rt] = __builtin_amdgcn_raw_buffer_load_b128(x, aoff + (4 * g * BP + rt * 16) * 16, 0, 16);
+                }
                 b[c] = bval ? bp[4 * g * WS] : z4;
             }
         }
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_fwd_kernel(PersistFwdAr
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
-            persist_core<RT, NC, WS4>((t & 1) ? rx1 : rx0, slab, H / 16 / p.nkw, wave, lane, acc);
+            persist_core<RT, NC, WS4>((t & 1) ? rx1 : rx0, slab, H / 16 / p.nkw, wave, lane, BP, acc);
             spill_partials<RT, NC>(red, acc, wave, lane);
         }
         __syncthreads();
@@ -437,6 +442,7 @@ struct PersistBwdArgs {
     float* dh;               // [B][H] in: dh_T, out: dh_0
     unsigned* sync;          // SYNC_WORDS words: timeout flag + sharded arrival counters; zeroed before the launch
     int T, B, H, nkw, nsh;
+    int rpg;                 // batch rows per row group (<= BP = 16 RT; 8 = half-filled 16-row tiles, half the operand pull)
 };
 
 template <int RT>
@@ -453,8 +459,8 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
     }
     const int grp = blockIdx.y;                       // row group: see the forward kernel
     const int row = tid / UB, u = tid % UB, j = j0 + u;
-    const int grow = grp * BP + row;
-    const bool mine = row < BP && grow < B;
+    const int grow = grp * p.rpg + row;
+    const bool mine = row < p.rpg && grow < B;
     const int64_t i = (int64_t)grow * H + j;
     float carry = mine ? p.dh[i] : 0.f;
     float* const dx0 = p.dx0 + (int64_t)grp * K * BP;
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
-                persist_core<RT, NC, UB>((s & 1) ? rx0 : rx1, slab, K / 16 / p.nkw, wave, lane, acc);     // step s-1 wrote dx[(s-1)&1]
+                persist_core<RT, NC, UB>((s & 1) ? rx0 : rx1, slab, K / 16 / p.nkw, wave, lane, p.rpg, acc);     // step s-1 wrote dx[(s-1)&1]
                 spill_partials<RT, NC>(red, acc, wave, lane);
             }
             __syncthreads();
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(NTH) void gru_small_persist_bwd_kernel(PersistBwdAr
             }
             static_assert(UB % 4 == 0, "a workgroup's units are whole quads of the operand");
             const __amdgpu_buffer_rsrc_t out = (s & 1) ? rx1 : rx0;
-            const bool lead = (u & 3) == 0;
+            const bool lead = (u & 3) == 0 && row < p.rpg;      // image rows beyond the group's rows are never read
             const int q = j / 4;                         // the same for the 4 lanes of a quad (j0 and H are multiples of 4)
             publish_quad(out, (int)(((int64_t)q * BP + row) * 16), drp, lead);
             publish_quad(out, (int)(((int64_t)(H / 4 + q) * BP + row) * 16), dzp, lead);
@@ -790,14 +796,23 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
     static const bool persist = []() { const char* e = getenv("LAED_GRU_PERSIST"); return !(e != nullptr && atoi(e) == 0); }();
     const int cu_limit = laed_persist_cu_limit(cu_budget);
     if (persist && NG == 1 && H / UB <= cu_limit) {
-        const PersistGroups pg = persist_groups(B, H / UB, cu_limit);
+        PersistGroups pg = persist_groups(B, H / UB, cu_limit);
+        int rpg = pg.rows;
+        // half-filled tiles: groups of 8 batch rows in 16-row images while 4 such groups cover the batch and still fit the CUs --
+        // a workgroup then pulls 8 rows x 3H floats per step instead of 16 (B = 30, H = 512: 49 KB instead of 98 KB)
+        static const bool half_ok = []() { const char* e = laed_exp_hook("LAED_GRU_HALF_GROUPS"); return !(e != nullptr && atoi(e) == 0); }();
+        if (half_ok && B <= 8 * MAX_PGROUPS && (int64_t)((B + 7) / 8) * (H / UB) <= cu_limit && pg.rows <= 16) {
+            pg.rows = 16;
+            pg.groups = (B + 7) / 8;
+            rpg = 8;
+        }
         const int PBP = pg.rows, PG = pg.groups;
         if (PG > MAX_PGROUPS) return laed_fail(LAED_E_SIZE, "gru_small: %d row groups (at most %d)", PG, MAX_PGROUPS);
         float* pdx[2] = {ws + (int64_t)3 * H * H, ws + (int64_t)3 * H * H + (int64_t)3 * H * PBP * PG};
         unsigned* sync = reinterpret_cast<unsigned*>(ws + (int64_t)3 * H * H + (int64_t)2 * 3 * H * PBP * PG);
         PersistBwdArgs a;
         a.dx0 = pdx[0]; a.dx1 = pdx[1]; a.wpT = wpT; a.dout = dout; a.hbuf = hbuf; a.hn = hn; a.gates = gates; a.dgh = dgh;
-        a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H); a.nsh = persist_shards();
+        a.dh = dh0; a.sync = sync; a.T = T; a.B = B; a.H = H; a.nkw = k_waves(3 * H); a.nsh = persist_shards(); a.rpg = rpg;
         size_t lds = ((size_t)3 * H * UB + (size_t)NW * PBP * UB) * sizeof(float);
         if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU
         if (lds <= 160 * 1024) {
