@@ -103,4 +103,5 @@ def _worker(rank, world, result_dir):
 
 def test_data_parallel_host_path_world2(tmp_path):
     mp.spawn(_worker, args=(2, str(tmp_path)), nprocs=2, join=True)
-    assert sorted(os.listdir(str(tmp_path))) == ["ok0", "ok1"]
+    # the rendezvous file may or may not outlive the group (the store removes it when its last user goes away)
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok0", "ok1"]

@@ -139,7 +139,7 @@ def check_library(path):
     try:
         funcs = disassemble(path, tmp)
     finally:
-        pass
+        shutil.rmtree(tmp, ignore_errors=True)
     bad = 0
     n_mfma = 0
     for name, ins in sorted(funcs.items()):
@@ -150,7 +150,6 @@ def check_library(path):
             bad += 1
             print("%s: %s\n    %#x  %s %s   <- %d wait state(s) after the MFMA at %#x wrote it (need %d)" %
                   (os.path.basename(path), name[:150], addr, op, args, d, src, NEED))
-    shutil.rmtree(tmp, ignore_errors=True)
     print("%s: %d kernels, %d MFMA instructions, %d finding(s)" % (os.path.basename(path), len(funcs), n_mfma, bad))
     return bad
 
