@@ -398,6 +398,13 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)           # per-rank NLL shares sum to the global NLL
             elapsed, nll = float(tmax[0]), float(t[1])
+        # what the host needs to ISSUE a step when nothing holds it back: a burst of 8 steps into an empty queue (over the
+        # whole timed loop a host that runs ahead is throttled by the launch queue, so `enqueue` above tends to the device time)
+        fence()
+        tb = time.perf_counter()
+        for _ in range(8):
+            step()
+        burst = (time.perf_counter() - tb) / 8
         # fwd+bwd (no Adam) step time, measured separately after the timed region
         fence()
         t1 = time.perf_counter()
@@ -442,6 +449,7 @@ def main():
         return {"value": round(tokens_per_step * args.steps / elapsed, 1), "ms_per_step": round(ms_per_step, 3),
                 "fwd_bwd_ms": round(fwd_bwd_ms, 3),
                 "host_enqueue_ms_per_step": round(enqueue / args.steps * 1e3, 3),
+                "host_issue_ms_per_step": round(burst * 1e3, 3),
                 "step_ms_device": {"median": round(per_step[len(per_step) // 2], 3),
                                    "p10": round(per_step[int(0.1 * (len(per_step) - 1))], 3),
                                    "p90": round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3),
@@ -465,6 +473,8 @@ def main():
             # host time to ISSUE a step (no sync inside the timed loop): well under ms_per_step = the host runs ahead and the GPU
             # never waits for a launch; close to it = the step is host-bound
             "host_enqueue_ms_per_step": main_res["host_enqueue_ms_per_step"],
+            # the same for a burst of 8 steps issued into an EMPTY queue: the host's own cost per step, without back-pressure
+            "host_issue_ms_per_step": main_res["host_issue_ms_per_step"],
             "encoder_tokens_per_s": main_res["encoder_tokens_per_s"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == "fp32" else "f32 (x W^T products as split-bf16 bf16x3, fp32 accumulate)",
             "data": "synthetic",
