@@ -1,4 +1,9 @@
-"""Timing-only ablations of the tiled GRU step kernel (-DGRU_EXP=n builds; results are wrong by design for n != 0).
+"""Timing of the tiled GRU step kernel (us per forward step, input GEMM negligible: E = 8) for one or more builds of the library.
+
+Ablation builds: compile csrc/gru.hip with -DGRU_EXP=n and link it with the other objects; the bits of n remove, from the
+scheduled K loop of interior blocks, 1 = the barrier, 2 = the staging (LDS stores + global loads), 4 = the fragment reads,
+and outside it 8 = the gate epilogue, 16 = the gate-operand loads (results are wrong by design for n != 0; only the clock
+counts).  GRU_EXP_B="512,4096" and GRU_EXP_H=1024 choose the shapes; LAED_GRU_WM forces a block geometry (gru.hip gru_step).
 usage: python tools/gru_exp.py lib.so ..."""
 import ctypes, os, sys, torch
 H = int(os.environ.get("GRU_EXP_H", "1024"))
