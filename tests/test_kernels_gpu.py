@@ -185,7 +185,11 @@ def test_gru_fwd_bwd(ops, O, T, B, E, H, with_h0):
 @pytest.mark.parametrize("T,B,E,H,with_h0", [(4, 1, 8, 64, True), (6, 30, 24, 128, False), (5, 33, 16, 192, True),
                                              (3, 64, 40, 1024, True), (9, 60, 200, 512, False), (1, 16, 8, 16, True),
                                              (4, 45, 12, 80, False), (5, 17, 16, 48, True), (7, 30, 200, 512, True),
-                                             (3, 8, 8, 1040, True), (2, 20, 8, 2064, False)])
+                                             (3, 8, 8, 1040, True), (2, 20, 8, 2064, False),
+                                             # row groups of the persistent backward: 8-row groups in half-filled tiles (B <= 32),
+                                             # a last group of one row, four full groups, shard counts that do not divide
+                                             (3, 9, 8, 32, True), (3, 25, 8, 64, False), (2, 32, 16, 96, True), (3, 24, 8, 256, True),
+                                             (2, 31, 8, 1000 // 16 * 16, True)])
 def test_gru_small_batch_kernels(ops, O, T, B, E, H, with_h0):
     """B <= 64 and H % 16 == 0 take gru_small.hip: packed operands, 4 / 8 units per workgroup; one persistent launch
     per direction with LDS-resident W_hh while all workgroups fit the chip (H <= 1024 forward, <= 2048 backward),
