@@ -286,8 +286,6 @@ def main():
     is_dialog = args.workload in ("AE-fixed", "ST-fixed")
     is_skip = args.workload == "ST-fixed"
     if is_dialog:
-        if world != 1:
-            raise SystemExit("AE-fixed / ST-fixed are single-GPU workloads (the dialog models are not data-parallel)")
         cfg = make_dialog_config(E, H, y, k, T, GB, is_skip)
         model = (StED if is_skip else AeED)(Corpus(V), cfg).cuda()
     else:

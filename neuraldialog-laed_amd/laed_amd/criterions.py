@@ -103,9 +103,14 @@ class CatKLLoss(_Loss):
     """sum_k q (log q - log p) per row, then mean over rows or sum / batch_size (criterions.py:93-109), on the
     wavefront row-reduction kernel `laed_cat_rows_fwd/bwd`.  log_py: 1-element, [k], [1,k], [R,1] or [R,k]."""
 
-    def forward(self, log_qy, log_py, batch_size=None, unit_average=False):
+    def forward(self, log_qy, log_py, batch_size=None, unit_average=False, dp_share=False):
+        """dp_share (no counterpart in the reference): the rows are this rank's shard of a data-parallel batch and the
+        result is the rank's SHARE of the global-batch value (the row weight is divided by the world size)."""
         log_qy = _rows2d(log_qy)
-        return ops.CatRowsFunction.apply(log_qy, log_py, _row_average(log_qy.shape[0], batch_size, unit_average))
+        w = _row_average(log_qy.shape[0], batch_size, unit_average)
+        if dp_share:
+            w = w / parallel.world_size()
+        return ops.CatRowsFunction.apply(log_qy, log_py, w)
 
 
 class Entropy(_Loss):

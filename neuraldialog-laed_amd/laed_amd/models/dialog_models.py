@@ -6,8 +6,11 @@ forward / valid_loss / model_sel_loss semantics and Pack keys as the reference. 
 kernels as DI-VAE / DI-VST; the one new kernel is the attribute-forcing head, which needs
 softmax(dec_outs) @ x_embedding.weight and gets it from laed_softmax_embed_{fwd,bwd} without forming [N,V].
 
-Limits (raise NotImplementedError): decoder attention (use_attn), LSTM cells, fix_batch, data
-parallelism for these two models.  valid_loss sums out of place (the reference's AeED mutates loss.nll in place,
+Limits (raise NotImplementedError): decoder attention (use_attn), LSTM cells, fix_batch.  Data parallelism (round 3): batch
+shards per rank as for DI-VAE / DI-VST; reg_kl / mi come from all-reduced batch statistics (BatchPriorKL), the 'word' NLLs
+divide by the global target counts (NLLEntropy's own exchanges), and every per-row mean (pi_kl, pi_nll, attribute_nll, the
+error rates) is taken over the global rows, so each rank holds its share of the global-batch value and the reducer's summed
+gradients are the global-batch gradients (tests/test_y_dp_gpu.py).  valid_loss sums out of place (the reference's AeED mutates loss.nll in place,
 dialog_models.py:280-284).
 """
 import itertools
@@ -25,22 +28,24 @@ from .model_bases import BaseModel
 
 
 def _mean_ce(log_p, ids):
-    """F.cross_entropy(logits, ids) given log_p = log_softmax(logits): mean_r -log_p[r, ids[r]] (tiny [B*y,k])."""
-    R = log_p.shape[0]
-    scale = torch.full((R,), 1.0 / R, device=log_p.device)
+    """F.cross_entropy(logits, ids) given log_p = log_softmax(logits): mean_r -log_p[r, ids[r]] (tiny [B*y,k]).
+    Under data parallelism the mean runs over the GLOBAL rows (equal shards): every rank holds its share of the
+    global-batch value, the shares add up to it, and the reducer's SUM of the gradients is the global-batch gradient."""
+    R = log_p.shape[0] * parallel.world_size()
+    scale = torch.full((log_p.shape[0],), 1.0 / R, device=log_p.device)
     return ops.NLLGatherFunction.apply(log_p, ids.reshape(-1).contiguous(), scale, -100)[0]
 
 
 def _err_rate(logits, ids):
-    return torch.mean((torch.max(logits, dim=1)[1] != ids.reshape(-1)).float())
+    """Share of the global-batch error rate (the local mean on one GPU); logged / model selection only."""
+    err = torch.mean((torch.max(logits, dim=1)[1] != ids.reshape(-1)).float())
+    return err if parallel.world_size() == 1 else err / parallel.world_size()
 
 
 class LAED(BaseModel):
     """Shared pieces of AeED / StED (dialog_models.py:21-187)."""
 
     def _build_shared(self, corpus, config):
-        if parallel.group() is not None:
-            raise NotImplementedError("AE-ED / ST-ED run on one GPU; data parallelism covers DI-VAE / DI-VST")
         self.vocab = corpus.vocab
         self.rev_vocab = corpus.rev_vocab
         self.vocab_size = len(self.vocab)
@@ -183,7 +188,7 @@ class LAED(BaseModel):
 
     def _encdec_losses(self, dec_outs, labels, log_qy, log_py, py_logits, y_id):
         enc_dec_nll = self.nll_loss(dec_outs, labels)
-        pi_kl = self.cat_kl_loss(log_qy.detach(), log_py, None, unit_average=True)
+        pi_kl = self.cat_kl_loss(log_qy.detach(), log_py, None, unit_average=True, dp_share=True)
         pi_nll = _mean_ce(log_py, y_id)
         pi_err = _err_rate(py_logits, y_id)
         if self.config.use_attribute:

@@ -188,6 +188,10 @@ class GradReducer(object):
 
     def _hook(self, p):
         g = p.grad
+        if g is None:
+            # frozen between forward and backward (AE-ED / ST-ED freeze the recognition side inside valid_loss, just before
+            # the flip step's backward): autograd dropped the gradient, on every rank alike -- nothing to reduce
+            return
         ev = None
         if self.stream is not None and g.is_cuda:
             ev = torch.cuda.Event()

@@ -138,3 +138,133 @@ def test_dp_path_on_rccl_one_rank_per_gpu(tmp_path, kind):
     world = _rccl_world()
     mp.spawn(_worker, args=(world, str(tmp_path), kind, "nccl"), nprocs=world, join=True)
     assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok%d" % r for r in range(world)]
+
+
+def _dialog_worker(rank, world, result_dir, name):
+    """AE-ED / ST-ED under data parallelism: phase-A forward / backward and three Adam steps on the batch sharded over
+    `world` ranks reproduce the reference's global-batch goldens (tests/golden/make_goldens_dialog.py)."""
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from helpers import load_golden, rel_err
+    from laed_amd import ops, parallel
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    from test_dialog_gpu import NOISE_ONLY, build, inject_u
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(result_dir, "rdzv"), rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60))
+    parallel.init()
+    ops.set_device_sharers(world)
+    G = load_golden(name)
+    model, cfg, kind = build(G)
+    model.train()
+    keys = [str(k) for k in G["meta/loss_keys"]]
+    B = G["in/outputs"].shape[0]
+    b0, b1 = parallel.shard_rows(B)
+    y = int(cfg.y_size)
+    feed = {k[3:]: G[k][b0:b1] for k in G.files if k.startswith("in/") and not k.startswith("in/u_")}
+    U = G["in/u_steps"]
+    GLOBAL = ("reg_kl", "mi")                      # batch statistics, all-reduced: the same on every rank
+    inject_u(model, U[0][b0 * y:b1 * y])
+    opt = model.get_optimizer(cfg)
+    assert opt.reducer is not None and opt.reducer.enabled
+    opt.zero_grad()
+    loss = model(feed, mode=TEACH_FORCE, return_latent=True)
+    for k in keys:
+        if loss[k] is None or ("A/" + k) not in G.files:
+            continue
+        ref = float(G["A/" + k])
+        if k in GLOBAL:
+            val = float(loss[k])
+        else:                                      # per-rank shares of a global-batch mean
+            t = loss[k].detach().reshape(1).clone()
+            dist.all_reduce(t)
+            val = float(t)
+        tol = 5e-3 if k == "mi" else 1e-4
+        assert abs(val - ref) <= 2e-6 + tol * abs(ref), (k, val, ref)
+    assert rel_err(loss["log_qy"].detach().cpu(), G["A/log_qy"][b0 * y:b1 * y]) < 1e-5
+    model.backward(0, loss)
+    opt.reducer.wait()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        g = G["A_grad/" + n]
+        if n in NOISE_ONLY:
+            continue
+        if g.size == 0:
+            assert p.grad is None, n
+        else:
+            assert p.grad is not None and rel_err(p.grad.cpu(), g) < 3e-4, (n, rel_err(p.grad.cpu(), g))
+    # three optimizer steps from the golden start (main.py:104-113 order)
+    model2, cfg, _ = build(G)
+    model2.train()
+    opt = model2.get_optimizer(cfg)
+    for s in range(3):
+        inject_u(model2, U[s][b0 * y:b1 * y])
+        opt.zero_grad()
+        loss = model2(feed, mode=TEACH_FORCE)
+        model2.backward(s, loss)
+        opt.step()
+    torch.cuda.synchronize()
+    def params_close(tag, atol):
+        for n, p in model2.named_parameters():
+            if n not in NOISE_ONLY:
+                d = float((p.detach().cpu() - torch.from_numpy(np.array(G[tag + n]))).abs().max())
+                assert d < atol, (tag, n, d)
+
+    def grads_close(tag):
+        for n, p in model2.named_parameters():
+            g = G[tag + n]
+            if n in NOISE_ONLY:
+                continue
+            if g.size == 0:
+                assert p.grad is None, (tag, n)
+            else:
+                assert p.grad is not None and rel_err(p.grad.cpu(), g) < 3e-4, (tag, n, rel_err(p.grad.cpu(), g))
+
+    params_close("A_p3/", 1e-4)
+    # the flip step: backward past freeze_step freezes the recognition side BEFORE the gradients are produced, so the
+    # reducer sees (and reduces) only what is still trainable; then the optimizer -- and its reducer -- are re-created
+    inject_u(model2, U[3][b0 * y:b1 * y])
+    opt.zero_grad()
+    loss = model2(feed, mode=TEACH_FORCE)
+    model2.backward(cfg.freeze_step + 1, loss)
+    opt.reducer.wait()
+    torch.cuda.synchronize()
+    assert model2.kl_w == 1.0 and model2.flush_valid
+    grads_close("flip_grad/")
+    opt.step()
+    params_close("flip_p/", 1.5e-4)
+    batch_cnt = cfg.freeze_step + 2
+    for s in range(3):
+        opt.zero_grad()
+        loss = model2(feed, mode=TEACH_FORCE)
+        if model2.flush_valid:
+            model2.flush_valid = False
+            old = opt.reducer
+            opt = model2.get_optimizer(cfg)
+            assert opt.reducer is not old and not old.enabled and opt.reducer.enabled
+        model2.zero_grad()
+        model2.backward(batch_cnt + s, loss)
+        if s == 0:
+            opt.reducer.wait()
+            torch.cuda.synchronize()
+            grads_close("B_grad/")
+        opt.step()
+    torch.cuda.synchronize()
+    params_close("B_p3/", 2e-4)
+    assert ops.gru_persist_timeouts() == 0
+    dist.destroy_process_group()
+    open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
+    faulthandler.cancel_dump_traceback_later()
+
+
+@pytest.mark.parametrize("name", ["aeed_mid", "sted_mid"])
+def test_dialog_models_dp_step_equals_reference_global_batch(tmp_path, name):
+    """AE-ED / ST-ED with the batch sharded over 2 ranks (sharing the box's GPU, gloo transport): loss shares add up to the
+    reference's global-batch values, the reduced gradients and the parameters after three Adam steps equal the goldens."""
+    mp.spawn(_dialog_worker, args=(2, str(tmp_path), name), nprocs=2, join=True)
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok0", "ok1"]
