@@ -140,7 +140,7 @@ def test_dp_path_on_rccl_one_rank_per_gpu(tmp_path, kind):
     assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok%d" % r for r in range(world)]
 
 
-def _dialog_worker(rank, world, result_dir, name):
+def _dialog_worker(rank, world, result_dir, name, backend="gloo"):
     """AE-ED / ST-ED under data parallelism: phase-A forward / backward and three Adam steps on the batch sharded over
     `world` ranks reproduce the reference's global-batch goldens (tests/golden/make_goldens_dialog.py)."""
     import faulthandler
@@ -154,11 +154,18 @@ def _dialog_worker(rank, world, result_dir, name):
     from laed_amd.enc2dec.decoders import TEACH_FORCE
     from test_dialog_gpu import NOISE_ONLY, build, inject_u
 
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="file://" + os.path.join(result_dir, "rdzv"), rank=rank, world_size=world,
-                            timeout=datetime.timedelta(seconds=60))
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    rdzv = dict(init_method="file://" + os.path.join(result_dir, "rdzv"), rank=rank, world_size=world,
+                timeout=datetime.timedelta(seconds=60))
+    if backend == "nccl":
+        os.environ["LAED_DP_FORCE"] = "1"          # keep the hooks / side stream / collectives on for a 1-rank group
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev), **rdzv)
+    else:
+        dist.init_process_group("gloo", **rdzv)
     parallel.init()
-    ops.set_device_sharers(world)
+    if backend != "nccl":
+        ops.set_device_sharers(world)
     G = load_golden(name)
     model, cfg, kind = build(G)
     model.train()
@@ -268,3 +275,12 @@ def test_dialog_models_dp_step_equals_reference_global_batch(tmp_path, name):
     reference's global-batch values, the reduced gradients and the parameters after three Adam steps equal the goldens."""
     mp.spawn(_dialog_worker, args=(2, str(tmp_path), name), nprocs=2, join=True)
     assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok0", "ok1"]
+
+
+@pytest.mark.parametrize("name", ["aeed_mid", "sted_mid"])
+def test_dialog_models_dp_path_on_rccl_one_rank_per_gpu(tmp_path, name):
+    """The same with backend "nccl" (RCCL), one rank per GPU the box has (a 1-rank group on the 1-GPU box): the reducer's
+    RCCL stream beside the models' two branch streams and the persistent recurrences."""
+    world = _rccl_world(batch=8)
+    mp.spawn(_dialog_worker, args=(world, str(tmp_path), name, "nccl"), nprocs=world, join=True)
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok%d" % r for r in range(world)]
