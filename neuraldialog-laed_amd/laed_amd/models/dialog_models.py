@@ -186,8 +186,18 @@ class LAED(BaseModel):
             for param in m.parameters():
                 param.requires_grad = False
 
-    def _encdec_losses(self, dec_outs, labels, log_qy, log_py, py_logits, y_id):
-        enc_dec_nll = self.nll_loss(dec_outs, labels)
+    def _latent_losses(self, log_qy, label_sets):
+        """-> ((reg_kl, b_pr, mi), [global non-PAD count or None per label set]): under data parallelism with 'word'
+        averaging the posterior's batch statistics and every decoder's target count travel in ONE all-reduce message
+        (as in sent_models._SentBase._latent_losses)."""
+        if parallel.group() is not None and self.nll_loss.avg_type == 'word':
+            local = torch.cat([self.nll_loss.local_count(lab) for lab in label_sets])
+            reg_kl, b_pr, mi, counts = self.bpr_loss(log_qy, None, extra=local)
+            return (reg_kl, b_pr, mi), [counts[i:i + 1] for i in range(len(label_sets))]
+        return self.bpr_loss(log_qy), [None] * len(label_sets)
+
+    def _encdec_losses(self, dec_outs, labels, log_qy, log_py, py_logits, y_id, count=None):
+        enc_dec_nll = self.nll_loss(dec_outs, labels, global_count=count)
         pi_kl = self.cat_kl_loss(log_qy.detach(), log_py, None, unit_average=True, dp_share=True)
         pi_nll = _mean_ce(log_py, y_id)
         pi_err = _err_rate(py_logits, y_id)
@@ -319,10 +329,10 @@ class AeED(LAED):
             return dec_ctx, labels
 
         log_qy = vae_resp.log_qy
-        vae_nll = self.nll_loss(vae_resp.dec_outs, labels)
-        reg_kl, _, mi = self.bpr_loss(log_qy)
+        (reg_kl, _, mi), (count,) = self._latent_losses(log_qy, [labels])      # both NLLs score the same targets
+        vae_nll = self.nll_loss(vae_resp.dec_outs, labels, global_count=count)
         enc_dec_nll, pi_kl, pi_nll, pi_err, attribute_nll, adv_err = self._encdec_losses(
-            dec_outs, labels, log_qy, log_py, py_logits, y_id)
+            dec_outs, labels, log_qy, log_py, py_logits, y_id, count)
         results = Pack(nll=enc_dec_nll, pi_kl=pi_kl, attribute_nll=attribute_nll, vae_nll=vae_nll, reg_kl=reg_kl,
                        mi=mi, pi_nll=pi_nll, pi_err=pi_err, adv_err=adv_err)
         if return_latent:
@@ -397,11 +407,12 @@ class StED(LAED):
             return dec_ctx, labels
 
         log_qy = vst_resp.log_qy
-        vst_prev_nll = self.nll_loss(vst_resp.prev_outs, prev_utts[:, 1:].contiguous())
-        vst_next_nll = self.nll_loss(vst_resp.next_outs, next_utts[:, 1:].contiguous())
-        reg_kl, _, mi = self.bpr_loss(log_qy)
+        prev_labels, next_labels = prev_utts[:, 1:].contiguous(), next_utts[:, 1:].contiguous()
+        (reg_kl, _, mi), (count, prev_count, next_count) = self._latent_losses(log_qy, [labels, prev_labels, next_labels])
+        vst_prev_nll = self.nll_loss(vst_resp.prev_outs, prev_labels, global_count=prev_count)
+        vst_next_nll = self.nll_loss(vst_resp.next_outs, next_labels, global_count=next_count)
         enc_dec_nll, pi_kl, pi_nll, pi_err, attribute_nll, adv_err = self._encdec_losses(
-            dec_outs, labels, log_qy, log_py, py_logits, y_id)
+            dec_outs, labels, log_qy, log_py, py_logits, y_id, count)
         results = Pack(nll=enc_dec_nll, pi_kl=pi_kl, pi_nll=pi_nll, attribute_nll=attribute_nll,
                        vst_prev_nll=vst_prev_nll, vst_next_nll=vst_next_nll, reg_kl=reg_kl, mi=mi, pi_err=pi_err,
                        adv_err=adv_err)

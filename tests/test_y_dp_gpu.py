@@ -180,7 +180,10 @@ def _dialog_worker(rank, world, result_dir, name, backend="gloo"):
     opt = model.get_optimizer(cfg)
     assert opt.reducer is not None and opt.reducer.enabled
     opt.zero_grad()
+    c0 = dict(parallel.COLLECTIVES)
     loss = model(feed, mode=TEACH_FORCE, return_latent=True)
+    # ONE forward exchange per step here too: the batch statistics and every decoder's target count in one message
+    assert parallel.COLLECTIVES["forward"] - c0["forward"] == 1, (parallel.COLLECTIVES, c0)
     for k in keys:
         if loss[k] is None or ("A/" + k) not in G.files:
             continue
