@@ -16,9 +16,11 @@ Flags the reference parses and never reads are accepted and ignored, as there (S
 the two sentence-model scripts.  Flags that select paths this build leaves out raise in the model constructors as before
 (`--rnn_cell lstm`, `--use_attn true`: NotImplementedError).  There is no CPU path: `--use_gpu false` is refused.
 
-One process, one GPU, like the reference's scripts.  Data parallelism lives one level down, at the step API (the models'
-forward exchange + `parallel.GradReducer`; `bench.py --gpus N`, tests/test_y_dp_gpu.py): the engine's
-loss bookkeeping and early stopping are per process and are not made rank-aware here.
+Data parallelism (new): started under a launcher --
+`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 <script> ...` -- every rank (one per GPU, RCCL over
+xGMI) builds the same model from the same seed and runs the same engine loop on its own rows of every batch; `--batch_size` is
+the GLOBAL batch and must divide by N.  Rank 0 alone creates the session directory, logs, writes checkpoints and, when training
+is over, produces the reports on its own.  `--forward_only true` needs one process only.
 """
 import argparse
 import json
@@ -153,15 +155,64 @@ def _dialog_reports(adv_batches):
     return run
 
 
+def _init_data_parallel(config):
+    """Under a torch.distributed launcher: one rank per GPU over RCCL.  -> (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else 1
+    if world <= 1:
+        return 0, 1
+    if config.forward_only:                                  # reports need one process: the others have nothing to do
+        return int(os.environ["RANK"]), -world
+    import torch.distributed as dist
+    from laed_amd import parallel
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    # LAED_DP_BACKEND=gloo: REHEARSAL of the multi-rank path on fewer GPUs than ranks (the ranks share the GPUs that exist;
+    # tests/test_cli_gpu.py on the one-GPU box) -- not a way to train
+    backend = os.environ.get("LAED_DP_BACKEND", "nccl")
+    if backend == "nccl" and local >= ndev:
+        raise SystemExit("rank %s has no GPU of its own (%d visible): one rank per GPU" % (os.environ["RANK"], ndev))
+    if config.batch_size % world:
+        raise SystemExit("--batch_size %d (the global batch) does not divide by %d ranks" % (config.batch_size, world))
+    torch.cuda.set_device(local % ndev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    parallel.init()
+    if world > ndev:
+        from laed_amd import ops
+        ops.set_device_sharers((world + ndev - 1) // ndev)
+    return dist.get_rank(), dist.get_world_size()
+
+
 def run(script, config):
-    """One driver script, start to finish (the `main(config)` of the reference script).  -> the paths it wrote."""
-    from laed_amd import evaluators, main as engine
+    """One driver script, start to finish (the `main(config)` of the reference script).  -> the paths it wrote (rank 0)."""
+    from laed_amd import evaluators, main as engine, parallel
     if not config.use_gpu:
         raise SystemExit("%s: --use_gpu false is not available: this build has no CPU path (the kernels are gfx950 HIP)" % script)
     if not torch.cuda.is_available():
         raise SystemExit("%s needs an MI355X" % script)
+    rank, world = _init_data_parallel(config)
+    if world < 0:                                            # forward_only under a launcher
+        if rank != 0:
+            return None
+        world = 1
     corpus_cls, loader_cls, model_cls, gen, eval_name, reports = _recipes()[script]
-    utils.prepare_dirs_loggers(config, script)
+    if world > 1:
+        import torch.distributed as dist
+        torch.manual_seed(int(getattr(config, "seed", 0)))   # identical replicas (the reference's scripts seed nothing)
+        box = [None]
+        if rank == 0:
+            utils.prepare_dirs_loggers(config, script)
+            box[0] = getattr(config, "session_dir", None)
+        else:
+            logging.getLogger().setLevel(logging.WARNING)    # one log: rank 0's
+        dist.broadcast_object_list(box, src=0)
+        config.session_dir = box[0]
+    else:
+        utils.prepare_dirs_loggers(config, script)
     corpus_client = corpus_cls(config)
     corpus = corpus_client.get_corpus()
     evaluator = evaluators.BleuEvaluator(eval_name)
@@ -178,6 +229,12 @@ def run(script, config):
             engine.train(model, feeds["train"], feeds["valid"], feeds["test"], config, evaluator, gen=gen)
         except KeyboardInterrupt:
             print("Training stopped by keyboard.")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                                       # rank 0's last checkpoint is on disk; every step has been joined
+        parallel.shutdown()                                  # from here on rank 0 works alone: no exchange in any forward
+        if rank != 0:
+            return None
     # the best checkpoint of the session: a plain state_dict (the reference's format; tensors only)
     model.load_state_dict(torch.load(paths["model"], map_location="cuda", weights_only=True))
     reports(model, feeds, config, evaluator, paths)
@@ -185,6 +242,9 @@ def run(script, config):
 
 
 def main(script, argv=None):
+    if os.environ.get("LAED_WATCHDOG"):                       # seconds: dump every thread's stack and exit (hang diagnosis)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LAED_WATCHDOG"]), exit=True)
     config, unparsed = get_config(script, argv)
     if unparsed:
         print("%s: ignoring unknown arguments %s" % (script, unparsed), file=sys.stderr)

@@ -15,6 +15,14 @@ What differs: loss scalars stay on the device until a report reads them (the ref
 step with `val.data[0]`, which no longer runs on 0-dim tensors), validation runs under `torch.no_grad()`, and the
 patience bookkeeping lives in `EarlyStopping`, which `tests/test_host_logic_cpu.py` drives through scripted
 validation losses without a GPU.
+New (the reference has no multi-GPU code): under data parallelism (`parallel.init()` called: one process per GPU) every rank
+runs this same loop over the same global batches, keeps its own rows of each (`parallel.shard_batch`), and sees the same
+GLOBAL loss values wherever a decision or a report depends on them -- validation reduces each batch's terms
+(`parallel.global_terms`), the training reports reduce lazily when they are printed -- so patience, phase changes and
+the stopping epoch are identical on every rank; rank 0 alone writes checkpoints (the preview generations run everywhere,
+which keeps the ranks' random-number counters in step; only rank 0's logger is expected to print them).  The order of
+each training pass is drawn from a per-pass seed so that nothing a single rank does in between can make the ranks disagree
+about it.  `tests/test_y_dp_gpu.py::test_engine_train_data_parallel_equals_single_process`.
 """
 import logging
 import os
@@ -22,6 +30,7 @@ import os
 import numpy as np
 import torch
 
+from . import parallel
 from .dataset.corpora import EOS, EOT, PAD
 from .enc2dec.decoders import GEN, TEACH_FORCE, DecoderRNN
 from .models.model_bases import summary
@@ -72,10 +81,30 @@ class _Series(object):
 
 
 class LossManager(object):
-    """Per-key running record of the 0-dim loss terms of a Pack plus the scalar that drives model selection."""
+    """Per-key running record of the 0-dim loss terms of a Pack plus the scalar that drives model selection.
 
-    def __init__(self):
+    `replicated` (data-parallel training only): the keys that are already global-batch values on every rank; every other
+    key holds this rank's SHARES, and whenever the record is read all shares parked since the last read are summed over
+    the ranks in one all-reduce (every rank reads at the same steps, so the collectives line up).  The step loop itself
+    never communicates for the sake of a report."""
+
+    def __init__(self, replicated=None):
+        self._replicated = replicated
         self.clear()
+
+    def _sync(self):
+        if self._replicated is None or parallel.group() is None:
+            return
+        todo = [s for k, s in self.losses.items() if k not in self._replicated and s._parked]
+        if not todo:
+            return
+        chunks = [torch.cat(s._parked).float() for s in todo]
+        vec = parallel.all_reduce_(torch.cat(chunks), kind="report").cpu().tolist()
+        at = 0
+        for s, c in zip(todo, chunks):
+            s._host.extend(vec[at:at + c.numel()])
+            s._parked = []
+            at += c.numel()
 
     def clear(self):
         self.losses = {}
@@ -93,6 +122,7 @@ class LossManager(object):
         return self.backward_losses.mean()
 
     def pprint(self, name, window=None, prefix=None):
+        self._sync()
         cells = []
         for key, series in self.losses.items():
             m = series.mean(window)
@@ -146,11 +176,12 @@ class EarlyStopping(object):
 # train / validate
 # ----------------------------------------------------------------------------------------------------------------
 def _batches(feed):
+    """The feed's batches; under data parallelism every rank walks the same global batches and keeps its own rows."""
     while True:
         batch = feed.next_batch()
         if batch is None:
             return
-        yield batch
+        yield parallel.shard_batch(batch)
 
 
 def _save_checkpoint(model, config):
@@ -190,14 +221,20 @@ def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=
     the preview is skipped."""
     if gen is None and evaluator is not None:
         gen = generate
+    dp = parallel.group() is not None
+    lead = parallel.rank() == 0
     stopper = EarlyStopping(config.max_epoch, config.early_stop, config.improve_threshold, config.patient_increase)
     optimizer = model.get_optimizer(config)
-    seen = LossManager()
+    seen = LossManager(replicated=getattr(model, "DP_REPLICATED", ()) if dp else None)
     step_no = 0
+    passes = 0
     model.train()
     logger.info(summary(model, show_weights=False))
     logger.info("Training starts: up to %d pseudo-epochs of %d batches", config.max_epoch, config.ckpt_step)
     while True:
+        if dp:          # every rank must draw the same order for this pass, whatever else has used numpy's generator since
+            np.random.seed((int(getattr(config, "seed", 0)) + 7919 * passes) & 0x7FFFFFFF)
+        passes += 1
         train_feed.epoch_init(config, verbose=stopper.epochs_done == 0, shuffle=True)
         for batch in _batches(train_feed):
             optimizer.zero_grad()
@@ -222,12 +259,14 @@ def train(model, train_feed, valid_feed, test_feed, config, evaluator=None, gen=
             logger.info("Pseudo-epoch %d done; %s", stopper.epochs_done + 1, seen.pprint("Train"))
             valid_loss = validate(model, valid_feed, config, step_no)
             check_persistent_recurrences(model, "pseudo-epoch %d" % (stopper.epochs_done + 1))
+            # data parallel: the preview runs on EVERY rank -- a GEN-mode forward exchanges nothing, the ranks' noise counters
+            # stay in step, and the other ranks would only wait for rank 0 at the next step's exchange anyway
             if gen is not None:
                 gen(model, test_feed, config, evaluator, num_batch=getattr(config, 'preview_batch_num', 1))
             is_best, extended = stopper.observe(valid_loss)
             if extended:
                 logger.info("Significant improvement: patience is now %s pseudo-epochs", stopper.patience)
-            if is_best and config.save_model:
+            if is_best and config.save_model and lead:
                 logger.info("New best validation loss %f, saved to %s", valid_loss, _save_checkpoint(model, config))
             if stopper.finished():
                 if stopper.epochs_done < config.max_epoch:
@@ -246,9 +285,11 @@ def validate(model, valid_feed, config, batch_cnt=None):
     model.eval()
     valid_feed.epoch_init(config, shuffle=False, verbose=True)
     seen = LossManager()
+    replicated = getattr(model, "DP_REPLICATED", ())
     with torch.no_grad():
         for batch in _batches(valid_feed):
-            loss = model(batch, mode=TEACH_FORCE)
+            # data parallel: the global-batch value of every term on every rank, so all ranks select and stop alike
+            loss = parallel.global_terms(model(batch, mode=TEACH_FORCE), replicated)
             seen.add_loss(loss)
             seen.add_backward_loss(model.model_sel_loss(loss, batch_cnt))
     valid_loss = seen.avg_loss()

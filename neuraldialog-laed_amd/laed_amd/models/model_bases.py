@@ -45,6 +45,11 @@ def _one_like(t):
 
 
 class BaseModel(nn.Module):
+    # Under data parallelism these loss terms are batch STATISTICS, formed from all-reduced sums and therefore already the
+    # global-batch value on every rank; every other scalar term of a model's loss Pack is the rank's share of one
+    # (parallel.global_terms, used by the engine's reports and model selection).
+    DP_REPLICATED = ("reg_kl", "mi", "bpr", "b_pr")
+
     def __init__(self, config):
         super(BaseModel, self).__init__()
         self.use_gpu = config.use_gpu

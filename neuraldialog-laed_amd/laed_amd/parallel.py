@@ -32,7 +32,7 @@ def shutdown():
     global _GROUP, _ENABLED
     _GROUP, _ENABLED = None, False
     _GLOO.clear()
-    COLLECTIVES["forward"] = COLLECTIVES["grad"] = 0
+    COLLECTIVES["forward"] = COLLECTIVES["grad"] = COLLECTIVES["report"] = 0
 
 
 def group():
@@ -50,8 +50,9 @@ def rank():
 
 _GLOO = {}
 # collectives issued since init(): "forward" = loss-statistics exchanges (ops.LatentLossFunction and friends, NLLEntropy),
-# "grad" = the GradReducer's.  Tests assert one forward exchange per DI-VAE / DI-VST step.
-COLLECTIVES = {"forward": 0, "grad": 0}
+# "grad" = the GradReducer's, "report" = the engine's loss reports (global_terms).  Tests assert one forward exchange per
+# DI-VAE / DI-VST step.
+COLLECTIVES = {"forward": 0, "grad": 0, "report": 0}
 
 
 def _is_gloo(group):
@@ -64,14 +65,19 @@ def all_reduce_(t, group=None, kind="forward"):
     """In-place SUM all-reduce of `t` over `group` (default: the DP group) on the current stream.
 
     Backend "nccl" (RCCL) is stream-ordered and needs nothing else.  Backend "gloo" is only the transport of the tests
-    and of bench.py's rehearsal mode (several ranks sharing one GPU); torch's gloo path for CUDA tensors never completes
-    on this ROCm stack when the collective is issued while the stream still has kernels in flight and another process
-    shares the GPU (tools/exp/gloo_shared_gpu.py reproduces it with plain torch matmuls; this was round 1's "4-rank
-    hang") -- so the stream is drained first."""
+    and of the rehearsal modes (several ranks sharing one GPU): torch's gloo path for CUDA tensors can fail to complete
+    on this ROCm stack when another process shares the GPU -- always when the collective is issued while the stream still
+    has kernels in flight (tools/exp/gloo_shared_gpu.py reproduces it with plain torch matmuls; round 1's "4-rank hang"),
+    and, seen once in round 3 with both ranks inside the same all_reduce of a 1-element tensor, now and then even after the
+    stream was drained.  A CUDA tensor therefore never reaches gloo: it is staged through a host copy (which also drains
+    the current stream), reduced there, and copied back."""
     group = _GROUP if group is None else group
-    if t.is_cuda and _is_gloo(group):
-        torch.cuda.current_stream(t.device).synchronize()
     COLLECTIVES[kind] += 1
+    if t.is_cuda and _is_gloo(group):
+        host = t.detach().cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+        return t
     dist.all_reduce(t, group=group)
     return t
 
@@ -89,6 +95,40 @@ def shard_rows(n):
         raise ValueError("global batch %d is not divisible by world size %d" % (n, ws))
     per = n // ws
     return rank() * per, (rank() + 1) * per
+
+
+def shard_batch(batch):
+    """This rank's contiguous rows of a loader batch (every entry of a loader's Pack is per-row: id matrices padded to the
+    GLOBAL batch's widths, length vectors, metas).  Identity on one GPU."""
+    if not _ENABLED or batch is None:
+        return batch
+    n = len(batch["outputs"])
+    b0, b1 = shard_rows(n)
+    out = type(batch)()
+    for key, val in batch.items():
+        if val is not None and hasattr(val, "__len__") and len(val) == n:
+            out[key] = val[b0:b1]
+        else:
+            out[key] = val
+    return out
+
+
+def global_terms(loss, replicated=()):
+    """The loss terms of one step as GLOBAL-batch values on every rank: under data parallelism a model's per-row terms (NLLs,
+    per-row KLs, error rates) are this rank's SHARE of the global-batch value and the batch statistics (`replicated`: reg_kl,
+    mi, bpr) are already global.  One small all-reduce carries every share.  Reporting / model selection only -- the training
+    step itself never needs it.  Identity on one GPU."""
+    if not _ENABLED:
+        return loss
+    keys = [k for k, v in loss.items() if torch.is_tensor(v) and v.numel() == 1 and k not in replicated]
+    if not keys:
+        return loss
+    vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
+    all_reduce_(vec, kind="report")
+    out = type(loss)(loss)
+    for i, k in enumerate(keys):
+        out[k] = vec[i]
+    return out
 
 
 class GradReducer(object):

@@ -287,3 +287,112 @@ def test_dialog_models_dp_path_on_rccl_one_rank_per_gpu(tmp_path, name):
     world = _rccl_world(batch=8)
     mp.spawn(_dialog_worker, args=(world, str(tmp_path), name, "nccl"), nprocs=world, join=True)
     assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("ok")) == ["ok%d" % r for r in range(world)]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the ENGINE under data parallelism: laed_amd.main.train on 2 ranks == the same run in one process
+# ----------------------------------------------------------------------------------------------------------------
+def _engine_worker(rank, world, result_dir, data_dir, tag):
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
+    for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import json
+    import logging
+    from argparse import Namespace
+    import torch.distributed as dist
+    from laed_amd import evaluators, main as engine, ops, parallel, utt_utils
+    from laed_amd.dataset import corpora, data_loaders
+    from laed_amd.models.sent_models import DiVAE
+
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(result_dir, "rdzv_" + tag), rank=rank,
+                                world_size=world, timeout=datetime.timedelta(seconds=60))
+        parallel.init()
+        ops.set_device_sharers(world)
+    session = os.path.join(result_dir, tag)
+    os.makedirs(session, exist_ok=True)
+    cfg = Namespace(data_dir=[data_dir], max_utt_len=20, max_dec_len=20, max_vocab_cnt=800, embed_size=32, num_layer=1,
+                    dropout=0.3, enc_cell_size=64, dec_cell_size=64, rnn_cell='gru', use_attn=False, beam_size=4,
+                    utt_type='rnn', bi_enc_cell=False, attn_type='cat', fix_batch=False, y_size=4, k=5, use_gpu=True,
+                    avg_type='word', use_mutual=True, use_reg_kl=True, train_prior=False, init_lr=0.002, op='adam',
+                    print_step=5, ckpt_step=10, max_epoch=3, early_stop=False, improve_threshold=0.996,
+                    patient_increase=2.0, save_model=True, session_dir=session, preview_batch_num=1, batch_size=32,
+                    backward_size=5, gen_type='greedy')
+    corpus = corpora.PTBCorpus(cfg)
+    ids = corpus.get_corpus()
+    feeds = [data_loaders.PTBDataLoader(n, ids[k], cfg) for n, k in (("Train", "train"), ("Valid", "valid"), ("Test", "test"))]
+    assert feeds[0].data_size // cfg.batch_size >= cfg.ckpt_step * cfg.max_epoch          # one pass over the data
+    torch.manual_seed(0)
+    np.random.seed(0)                # the single-process run shuffles from here; the DP engine seeds pass 0 with 0 itself
+    model = DiVAE(corpus, cfg).cuda()
+
+    class Keep(logging.Handler):
+        lines = []
+
+        def emit(self, record):
+            Keep.lines.append(record.getMessage())
+    root = logging.getLogger()
+    root.addHandler(Keep())
+    root.setLevel(logging.INFO)
+    c0 = dict(parallel.COLLECTIVES)
+    best = engine.train(model, feeds[0], feeds[1], feeds[2], cfg, evaluators.BleuEvaluator("dp"), gen=utt_utils.generate)
+    torch.cuda.synchronize()
+    assert ops.gru_persist_timeouts() == 0
+    valid = [l for l in Keep.lines if l.startswith("Valid nll")]
+    train = [l for l in Keep.lines if "Train " in l and ("/10-(" in l or l.startswith("Pseudo-epoch"))]
+    assert len(valid) == 3 and len(train) == 9, (valid, train)
+    if world > 1:
+        # reports: one exchange per validation batch and one per printed training report that has new steps to show (the
+        # "Pseudo-epoch done" line re-reads what the print just before it reduced); the step itself: one forward exchange
+        n_valid_batches = feeds[1].data_size // cfg.batch_size
+        assert parallel.COLLECTIVES["report"] - c0["report"] == 3 * n_valid_batches + 6, parallel.COLLECTIVES
+        assert parallel.COLLECTIVES["forward"] - c0["forward"] == 30 + 3 * n_valid_batches, parallel.COLLECTIVES
+    json.dump({"best": best, "valid": valid, "train": train}, open(os.path.join(result_dir, "%s_%d.json" % (tag, rank)), "w"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+def _numbers(line):
+    import re
+    return [float(x) for x in re.findall(r"-?\d+\.\d+", line)]
+
+
+def test_engine_train_data_parallel_equals_single_process(tmp_path):
+    """laed_amd.main.train (three pseudo-epochs: training reports, validation, preview generation, best-checkpoint saving)
+    with the batch of 32 sharded over 2 ranks (sharing the box's GPU, gloo transport) against the same run in ONE process:
+    the same validation losses and training reports on BOTH ranks (global values, not shares), the same best loss, rank 0's
+    checkpoint equal to the single-process one, and the exchange counts the engine is meant to add (one per validation batch,
+    one per printed report).  Dropout and the Gumbel noise are on: their counter-based generators are keyed by global row."""
+    import json
+    sys.path.insert(0, HERE)
+    from helpers import load_golden
+    G = load_golden("corpora")
+    ptb = tmp_path / "ptb"
+    ptb.mkdir()
+    for s in ("train", "valid", "test"):
+        text = G["daily_dialog/inputs/%s/txt" % s].tobytes().decode("utf-8", errors="ignore").lower()
+        utts = [u.strip() for line in text.splitlines() for u in line.split("__eou__") if u.strip()]
+        (ptb / ("ptb.%s.txt" % s)).write_text("".join(" %s \n" % u for u in utts), encoding="utf-8")
+    mp.spawn(_engine_worker, args=(1, str(tmp_path), str(ptb), "one"), nprocs=1, join=True)
+    mp.spawn(_engine_worker, args=(2, str(tmp_path), str(ptb), "two"), nprocs=2, join=True)
+    one = json.load(open(str(tmp_path / "one_0.json")))
+    r0 = json.load(open(str(tmp_path / "two_0.json")))
+    r1 = json.load(open(str(tmp_path / "two_1.json")))
+    assert r0["valid"] == r1["valid"] and r0["train"] == r1["train"] and r0["best"] == r1["best"]       # ranks agree exactly
+    for a, b in zip(one["valid"] + one["train"], r0["valid"] + r0["train"]):
+        na, nb = _numbers(a), _numbers(b)
+        assert len(na) == len(nb) >= 5
+        for x, y in zip(na, nb):
+            assert abs(x - y) <= 2e-3 + 2e-3 * abs(x), (a, b)
+    assert abs(one["best"] - r0["best"]) <= 1e-3 * abs(one["best"])
+    sd1 = torch.load(str(tmp_path / "one" / "model"), weights_only=True, map_location="cpu")
+    sd2 = torch.load(str(tmp_path / "two" / "model"), weights_only=True, map_location="cpu")
+    assert list(sd1) == list(sd2)
+    for k in sd1:
+        d = (sd1[k] - sd2[k]).abs()
+        assert float(d.mean()) < 2e-4 and float(d.max()) < 2e-2, (k, float(d.mean()), float(d.max()))
