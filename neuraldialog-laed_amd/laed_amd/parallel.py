@@ -100,7 +100,7 @@ def shard_rows(n):
 def shard_batch(batch):
     """This rank's contiguous rows of a loader batch (every entry of a loader's Pack is per-row: id matrices padded to the
     GLOBAL batch's widths, length vectors, metas).  Identity on one GPU."""
-    if not _ENABLED or batch is None:
+    if not _ENABLED or batch is None or not hasattr(batch.get("outputs"), "__len__"):
         return batch
     n = len(batch["outputs"])
     b0, b1 = shard_rows(n)

@@ -1,5 +1,6 @@
 """world_size-2 data-parallel host path on CPU (gloo): gradient reducer, sharding, and the two forward
-exchanges (global non-PAD count for 'word' NLL, batch-mean posterior for BPR) reproduce single-process values."""
+exchanges (global non-PAD count for 'word' NLL, batch-mean posterior for BPR) reproduce single-process values; the engine's
+train / validate loop on a scripted model takes the same decisions and logs the same global numbers on both ranks."""
 import datetime
 import os
 import sys
@@ -95,10 +96,78 @@ def _worker(rank, world, result_dir):
     l = torch.log(q_sum / B + 1e-15)
     bpr = (torch.exp(l) * (l - np.log(1.0 / k))).sum(1).mean()
     assert abs(float(bpr) - float(G["out/bpr"])) < 1e-6 + 1e-4 * abs(float(G["out/bpr"]))
+    # 3. the ENGINE under data parallelism (laed_amd.main.train / validate; scripted model, tests/engine_stub.py): every
+    # rank's nll is a SHARE ((rank + 1) / 3 of the scripted value), reg_kl a replicated batch statistic.  Both ranks must
+    # log the global values, take the same decisions, and only rank 0 may save -- i.e. reproduce the one-process run.
+    dp_lines, dp_best, dp_saved = _run_engine(result_dir, "dp%d" % rank, share=(rank + 1) / 3.0)
+    batch = parallel.shard_batch({"outputs": np.arange(12).reshape(6, 2), "output_lens": [2] * 6, "metas": list("abcdef"),
+                                  "flag": None})
+    assert batch["outputs"].tolist() == np.arange(12).reshape(6, 2)[3 * rank:3 * rank + 3].tolist()
+    assert batch["metas"] == list("abcdef")[3 * rank:3 * rank + 3] and batch["output_lens"] == [2] * 3 and batch["flag"] is None
     parallel.shutdown()
     assert parallel.group() is None and parallel.world_size() == 1
+    one_lines, one_best, one_saved = _run_engine(result_dir, "one%d" % rank, share=1.0)
+    assert len(dp_lines) == len(one_lines) > 10
+    for a, b in zip(dp_lines, one_lines):
+        na, nb = _numbers(a), _numbers(b)
+        assert _words(a) == _words(b) and len(na) == len(nb), (a, b)
+        assert all(abs(x - y) <= 2e-3 for x, y in zip(na, nb)), (a, b)
+    assert abs(dp_best - one_best) < 1e-5 and one_saved and dp_saved == (rank == 0)
     dist.destroy_process_group()
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
+
+
+def _numbers(line):
+    import re
+    return [float(x) for x in re.findall(r"-?\d+\.\d+", line)]
+
+
+def _words(line):
+    import re
+    return re.sub(r"-?\d+\.\d+", "#", line)
+
+
+def _run_engine(result_dir, tag, share):
+    """engine.train on the scripted model: 4 pseudo-epochs that straddle the feed's passes, 3 validation batches per pass,
+    a report every step, a phase change (flush_valid) at the 4th forward, checkpoints on.  -> (log lines, best, saved?)"""
+    import logging
+    from engine_stub import ScriptedFeed, ScriptedModel, engine_config
+    from laed_amd import main as engine
+
+    class Shares(ScriptedModel):
+        DP_REPLICATED = ("reg_kl",)
+
+        def __call__(self, batch, mode=None):
+            out = ScriptedModel.__call__(self, batch, mode)
+            out["nll"] = out["nll"] * share
+            return out
+
+        def model_sel_loss(self, loss, batch_cnt):
+            return loss["nll"] + loss.get("reg_kl", 0.0)
+
+    session = os.path.join(result_dir, tag)
+    os.makedirs(session)
+    model = Shares([4.0, 3.5, 3.6, 3.0], (2.0, 1.5, 1.0, 0.5, 0.25), flush_at=4, shape=())
+    cfg = engine_config(session, max_epoch=4, print_step=1, save_model=True)
+    lines = []
+
+    class Keep(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+    root = logging.getLogger()
+    keep = Keep()
+    root.addHandler(keep)
+    level = root.level
+    root.setLevel(logging.INFO)
+    try:
+        best = engine.train(model, ScriptedFeed("Train", 3, model), ScriptedFeed("Valid", 3, model),
+                            ScriptedFeed("Test", 1, model), cfg)
+    finally:
+        root.removeHandler(keep)
+        root.setLevel(level)
+    assert model.events.count("get_optimizer") == 2                      # the phase change rebuilt it, on every rank
+    keep = [l for l in lines if ("nll" in l or "alidation" in l or "atience" in l) and "saved to" not in l]      # rank 0's own
+    return keep, best, os.path.exists(os.path.join(session, "model"))
 
 
 def test_data_parallel_host_path_world2(tmp_path):
