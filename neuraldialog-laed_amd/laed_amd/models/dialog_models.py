@@ -292,6 +292,16 @@ class AeED(LAED):
             return enc_loss
         return vae_loss
 
+    def loss_terms(self, loss, batch_cnt=None):
+        """What valid_loss adds up on this step (BaseModel.backward roots the backward pass at the terms and skips the adds);
+        the step that changes phase goes through valid_loss itself, which freezes the recognition side."""
+        if batch_cnt is not None and batch_cnt > self.config.freeze_step:
+            if self.kl_w == 0.0:
+                return None
+            terms = [loss.nll, loss.pi_nll if self.config.greedy_q else loss.pi_kl]
+            return terms + ([(loss.attribute_nll, 0.1)] if self.config.use_attribute else [])
+        return [loss.vae_nll, loss.reg_kl]
+
     def pxz_forward(self, batch_size, results, out_utts, mode, gen_type):
         dec_init_state = self.x_init_connector(results.sample_y)
         dec_outs, dec_last, dec_ctx = self.x_decoder(batch_size, out_utts[:, 0:-1], dec_init_state, mode=mode,
@@ -366,6 +376,15 @@ class StED(LAED):
                               self.next_decoder])
             return enc_loss
         return vst_loss
+
+    def loss_terms(self, loss, batch_cnt=None):
+        """See AeED.loss_terms."""
+        if batch_cnt is not None and batch_cnt > self.config.freeze_step:
+            if self.kl_w == 0.0:
+                return None
+            terms = [loss.nll, loss.pi_nll if self.config.greedy_q else loss.pi_kl]
+            return terms + ([loss.attribute_nll] if self.config.use_attribute else [])
+        return [loss.vst_prev_nll, loss.vst_next_nll] + ([loss.reg_kl] if self.config.use_reg_kl else [])
 
     def pxz_forward(self, batch_size, results, prev_utts, next_utts, mode, gen_type):
         dec_init_state = self.x_init_connector(results.sample_y)

@@ -35,12 +35,12 @@ def summary(model, show_weights=True, show_parameters=True):
 _ONES = {}
 
 
-def _one_like(t):
-    """A cached 0-dim constant 1 on t's device (the seed of a backward pass; never written)."""
-    key = (t.device, t.dtype)
+def _one_like(t, weight=1.0):
+    """A cached 0-dim constant `weight` (1 by default) on t's device: the seed of a backward pass; never written."""
+    key = (t.device, t.dtype, float(weight))
     one = _ONES.get(key)
     if one is None:
-        one = _ONES[key] = torch.ones((), device=t.device, dtype=t.dtype)
+        one = _ONES[key] = torch.full((), float(weight), device=t.device, dtype=t.dtype)
     return one
 
 
@@ -73,15 +73,17 @@ class BaseModel(nn.Module):
         the roots themselves, each seeded with a cached constant 1: the same gradients, without the add kernel(s) that form
         the sum and the fill that seeds it -- three to four launches of a 1.5 ms step."""
         terms = self.loss_terms(loss, batch_cnt)
-        if terms and all(torch.is_tensor(t) and t.is_cuda and t.dim() == 0 and t.requires_grad for t in terms):
-            torch.autograd.backward(terms, [_one_like(t) for t in terms])
-            return
+        if terms:
+            pairs = [t if isinstance(t, tuple) else (t, 1.0) for t in terms]
+            if all(torch.is_tensor(t) and t.is_cuda and t.dim() == 0 and t.requires_grad for t, _ in pairs):
+                torch.autograd.backward([t for t, _ in pairs], [_one_like(t, w) for t, w in pairs])
+                return
         total_loss = self.valid_loss(loss, batch_cnt)
         total_loss.backward()
 
     def loss_terms(self, loss, batch_cnt=None):
-        """The tensors whose sum is valid_loss(loss, batch_cnt), or None where valid_loss does more than add (phase
-        switches, weights): backward() then goes through valid_loss itself."""
+        """The terms whose (weighted) sum is valid_loss(loss, batch_cnt) -- tensors, or (tensor, weight) pairs -- or None
+        where valid_loss does more than that on this step (a phase switch): backward() then goes through valid_loss."""
         return None
 
     def valid_loss(self, loss, batch_cnt=None):

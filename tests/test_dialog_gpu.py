@@ -215,3 +215,43 @@ def test_softmax_embed_kernel_vs_torch(N, H, V, E, chunk, bare):
     assert rel_err(o2.detach().cpu(), ref.detach()) < 1e-5
     for key in ("h", "W", "b", "We"):
         assert rel_err(p[key].grad.cpu(), t[key].grad) < 2e-5, key
+
+
+@pytest.mark.parametrize("name", ["aeed_tiny", "sted_tiny"])
+def test_backward_rooted_at_the_loss_terms_equals_backward_of_valid_loss(name):
+    """AeED / StED.loss_terms: in the pretraining phase and in the encoder-decoder phase the backward pass rooted at the
+    (weighted) terms gives bit-identical gradients to valid_loss(...).backward() and the terms add up to valid_loss; the
+    step that changes phase returns None (valid_loss must run there: it freezes the recognition side)."""
+    from laed_amd.enc2dec.decoders import TEACH_FORCE
+    G = load_golden(name)
+    feed = {k[3:]: G[k] for k in G.files if k.startswith("in/") and not k.startswith("in/u_")}
+
+    def weighted_sum(terms):
+        return float(sum((t[0] * t[1]) if isinstance(t, tuple) else t for t in terms).detach())
+
+    for phase in ("A", "B"):
+        grads = []
+        for rooted in (True, False):
+            model, cfg, kind = build(G)
+            model.train()
+            inject_u(model, G["in/u_steps"][0])
+            cnt = 0
+            if phase == "B":                                   # go through the flip the way the engine does
+                assert model.loss_terms(model(feed, mode=TEACH_FORCE), cfg.freeze_step + 1) is None
+                model.backward(cfg.freeze_step + 1, model(feed, mode=TEACH_FORCE))
+                assert model.kl_w == 1.0
+                model.zero_grad()
+                cnt = cfg.freeze_step + 2
+            loss = model(feed, mode=TEACH_FORCE)
+            terms = model.loss_terms(loss, cnt)
+            assert terms is not None and len(terms) >= 2
+            assert abs(weighted_sum(terms) - float(model.valid_loss(loss, cnt).detach())) <= 1e-6 * abs(weighted_sum(terms))
+            if rooted:
+                model.backward(cnt, loss)
+            else:
+                model.valid_loss(loss, cnt).backward()
+            torch.cuda.synchronize()
+            grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 5, phase
+        for k in grads[0]:
+            assert torch.equal(grads[0][k], grads[1][k]), (phase, k)
