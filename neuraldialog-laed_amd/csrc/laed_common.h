@@ -152,6 +152,19 @@ int laed_gru_small_bwd(const float* w_hh, const float* hbuf, const float* hn, co
 // both, relative < 4e-7 for tanh everywhere and for sigmoid on |x| <= 4 (its far negative tail carries the rounding of
 // x log2 e: relative |x| 1e-7 on values below 2e-2).  libm's expf / tanhf / IEEE division cost ~140 instructions per (row, unit) with two
 // data-dependent branches; these cost ~35.
+// Streaming (non-temporal, `nt`) 16-byte accesses for data that is touched once per pass and is far larger than any cache
+// (the softmax-CE pass over an [rows][V] logits chunk: 8 GB): 3.5 % off that kernel (3083 -> 2975 us per 40960-row chunk,
+// tools/exp/rows_ab.sh), neutral where the chunk is small enough to stay in the Infinity Cache (V = 10 k, B = 30).
+__device__ __forceinline__ float4 load_stream(const float4* p) {
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void store_stream(float4* p, float4 v) {
+    f32x4 t;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
+
 __device__ __forceinline__ float sigmoidf_acc(float x) {
     // 1 / (1 + 2^(-x log2 e)): 2^(+big) = inf -> 0, 2^(-big) = 0 -> 1, NaN propagates
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));

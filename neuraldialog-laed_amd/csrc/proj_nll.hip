@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void proj_rows_reg_kernel(float* __restrict__
             const int i = tid + 1024 * c;
             x[c] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             if (i < n4) {
-                x[c] = Lr4[i];
+                x[c] = load_stream(&Lr4[i]);           // read once, rewritten below: no reuse for any cache to keep
                 const int c0 = 4 * i;                  // columns >= V are workspace padding
                 if (c0 + 3 >= V) {
                     if (c0 >= V) x[c].x = -INFINITY;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(1024) void proj_rows_reg_kernel(float* __restrict__
                         if (lab_i == c0) v.x -= g; else if (lab_i == c0 + 1) v.y -= g;
                         else if (lab_i == c0 + 2) v.z -= g; else v.w -= g;
                     }
-                    Lr4[i] = v;
+                    store_stream(&Lr4[i], v);
                 }
             }
         } else if (MODE == MODE_LOGP) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of proj_rows_reg_kernel between the product library and the hooks library (whatever differs between the two builds),
+# A/B of one kernel (AB_KERNEL = substring of its name; default proj_rows_reg_kernel) between the product library and the hooks library (whatever differs between the two builds),
 # alternated on one box: kernel average from rocprofv3 --stats over a short S-fixed run, and the step time.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -12,8 +12,10 @@ for i in 1 2; do for lib in product hooks; do
   python - $O/${lib}_$i $O/${lib}_$i.json $lib <<'PY'
 import csv, glob, json, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0])))
-r = [x for x in rows if "proj_rows_reg_kernel" in x["Name"]][0]
+import os
+pat = os.environ.get("AB_KERNEL", "proj_rows_reg_kernel")
+r = [x for x in rows if pat in x["Name"]][0]
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-print("%-8s proj_rows avg %.1f us (%s calls)   step %.2f ms  nll %.5f" % (sys.argv[3], float(r["AverageNs"]) / 1e3, r["Calls"], d["ms_per_step"], d["final_nll"]))
+print(("%-8s " + pat[:60] + " avg %.1f us (%s calls)   step %.2f ms  nll %.5f") % (sys.argv[3], float(r["AverageNs"]) / 1e3, r["Calls"], d["ms_per_step"], d["final_nll"]))
 PY
 done; done
