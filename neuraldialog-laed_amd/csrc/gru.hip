@@ -23,6 +23,15 @@ __device__ __forceinline__ float ldb(const float* base, unsigned byte_off) {
 __device__ __forceinline__ void stb(float* base, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// the same for data that is touched ONCE per pass -- the input projection's gi rows on their way in, the gates and hn kept for the
+// backward pass on their way out: streaming (nt) accesses, so that W_hh and h_{t-1}, which every block re-reads, keep the L2
+// (214 -> 211 us per step at B = 4096, alternated on one box; bit-identical)
+__device__ __forceinline__ float ldb_s(const float* base, unsigned byte_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+__device__ __forceinline__ void stb_s(float* base, unsigned byte_off, float v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off));
+}
 
 struct GruStepArgs {
     const float* hprev;   // [B][H]
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
 #if defined(GRU_EXP) && (GRU_EXP & 16)
         pre[ee][k] = bhr;
 #else
-        pre[ee][k] = k < 3 ? ldb(p.gates, og + dr * 3u * hb + k * hb) : ldb(p.hprev, oh + dr * hb);
+        pre[ee][k] = k < 3 ? ldb_s(p.gates, og + dr * 3u * hb + k * hb) : ldb(p.hprev, oh + dr * hb);
 #endif
     };
     // The 4 EPW gate operands per lane are 67 MB per step at B = 4096 -- a third of what the step moves.  Issued first
@@ -333,8 +342,8 @@ __global__ __launch_bounds__(NT) void gru_step_fwd_kernel(GruStepArgs p) {
                 const unsigned a = og + dr * 3u * hb, b = oh + dr * hb;
                 stb(p.hout, b, (1.0f - z) * n + z * pre[ee][3]);
                 if (KEEP) {
-                    stb(p.gates, a, r); stb(p.gates, a + hb, z); stb(p.gates, a + 2u * hb, n);
-                    stb(p.hn, b, ghn);
+                    stb_s(p.gates, a, r); stb_s(p.gates, a + hb, z); stb_s(p.gates, a + 2u * hb, n);
+                    stb_s(p.hn, b, ghn);
                 }
             }
             return;
@@ -455,14 +464,16 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(GruBwdStepArgs p) {
         if (p.dout != nullptr) dh += p.dout[i];
         float* g = p.gates + b * 3 * p.H;
         float* d = p.dgh + b * 3 * p.H;
-        const float r = g[j], z = g[p.H + j], nn = g[2 * p.H + j];
-        const float hn = p.hn[i], hp = p.hprev[i];
+        // r, z, n and hn were kept by the forward pass long ago and are read once; d(gi) written below is read by the post-loop
+        // products only: streaming accesses (42.0 -> 40.9 us per step at B = 4096, H = 1024).  d(gh) feeds the very next GEMM.
+        const float r = __builtin_nontemporal_load(g + j), z = __builtin_nontemporal_load(g + p.H + j), nn = __builtin_nontemporal_load(g + 2 * p.H + j);
+        const float hn = __builtin_nontemporal_load(p.hn + i), hp = p.hprev[i];
         const float dn = dh * (1.0f - z);
         const float dz = dh * (hp - nn);
         const float dnp = dn * (1.0f - nn * nn);
         const float dzp = dz * z * (1.0f - z);
         const float drp = dnp * hn * r * (1.0f - r);
-        g[j] = drp; g[p.H + j] = dzp; g[2 * p.H + j] = dnp;
+        __builtin_nontemporal_store(drp, g + j); __builtin_nontemporal_store(dzp, g + p.H + j); __builtin_nontemporal_store(dnp, g + 2 * p.H + j);
         d[j] = drp; d[p.H + j] = dzp; d[2 * p.H + j] = dnp * r;
         p.dh[i] = dh * z;
     }
