@@ -21,6 +21,8 @@ Data parallelism (new): started under a launcher --
 xGMI) builds the same model from the same seed and runs the same engine loop on its own rows of every batch; `--batch_size` is
 the GLOBAL batch and must divide by N.  Rank 0 alone creates the session directory, logs, writes checkpoints and, when training
 is over, produces the reports on its own.  `--forward_only true` needs one process only.
+Environment (diagnostics only): `LAED_WATCHDOG=<seconds>` dumps every thread's stack and exits if the script is still running
+then (where is it stuck?); `LAED_DP_BACKEND=gloo` rehearses the multi-rank path with the ranks sharing the GPUs that exist.
 """
 import argparse
 import json

@@ -138,10 +138,15 @@ def test_script_under_a_launcher_trains_data_parallel(script, data_dirs, tmp_pat
     pkg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "neuraldialog-laed_amd")
     # a rank still running after 100 s dumps its threads' stacks and exits: a failure with a place, not a silent hang
     env = dict(os.environ, LAED_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", LAED_WATCHDOG="100")
+    import socket
+    probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
     sent = script == "ptb-utt.py"
     flags = [a if a != "30" else "32" for a in SENT] if sent else DIALOG
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(pkg, script), "--data_dir", data_dirs[script], "--log_dir",
+           "--master-port", str(port), os.path.join(pkg, script), "--data_dir", data_dirs[script], "--log_dir",
            str(tmp_path / "logs")] + flags
     with open(str(tmp_path / "run.log"), "w") as out:
         rc = subprocess.run(cmd, env=env, stdin=subprocess.DEVNULL, stdout=out, stderr=subprocess.STDOUT, timeout=150).returncode
