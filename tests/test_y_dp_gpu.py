@@ -292,7 +292,7 @@ def test_dialog_models_dp_path_on_rccl_one_rank_per_gpu(tmp_path, name):
 # ----------------------------------------------------------------------------------------------------------------
 # the ENGINE under data parallelism: laed_amd.main.train on 2 ranks == the same run in one process
 # ----------------------------------------------------------------------------------------------------------------
-def _engine_worker(rank, world, result_dir, data_dir, tag):
+def _engine_worker(rank, world, result_dir, data_dir, tag, kind="divae"):
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)
     for p in (ROOT, os.path.join(ROOT, "neuraldialog-laed_amd"), HERE):
@@ -321,13 +321,25 @@ def _engine_worker(rank, world, result_dir, data_dir, tag):
                     print_step=5, ckpt_step=10, max_epoch=3, early_stop=False, improve_threshold=0.996,
                     patient_increase=2.0, save_model=True, session_dir=session, preview_batch_num=1, batch_size=32,
                     backward_size=5, gen_type='greedy')
-    corpus = corpora.PTBCorpus(cfg)
-    ids = corpus.get_corpus()
-    feeds = [data_loaders.PTBDataLoader(n, ids[k], cfg) for n, k in (("Train", "train"), ("Valid", "valid"), ("Test", "test"))]
+    if kind == "sted":               # ST-ED on the Stanford fixture: the phase change (freeze, new optimizer + reducer) at step 18
+        from laed_amd import dialog_utils
+        from laed_amd.models.dialog_models import StED
+        for k, v in dict(utt_cell_size=32, ctx_cell_size=64, bi_ctx_cell=False, use_attribute=True, greedy_q=True, y_size=3,
+                         include_eod=True, freeze_step=18, batch_size=8, ckpt_step=10, max_epoch=3, backward_size=10).items():
+            setattr(cfg, k, v)
+        corpus = corpora.StanfordCorpus(cfg)
+        ids = corpus.get_corpus()
+        feeds = [data_loaders.SMDDialogSkipLoader(n, ids[k], cfg) for n, k in (("Train", "train"), ("Valid", "valid"), ("Test", "test"))]
+        gen = dialog_utils.generate_with_adv
+    else:
+        corpus = corpora.PTBCorpus(cfg)
+        ids = corpus.get_corpus()
+        feeds = [data_loaders.PTBDataLoader(n, ids[k], cfg) for n, k in (("Train", "train"), ("Valid", "valid"), ("Test", "test"))]
+        gen = utt_utils.generate
     assert feeds[0].data_size // cfg.batch_size >= cfg.ckpt_step * cfg.max_epoch          # one pass over the data
     torch.manual_seed(0)
     np.random.seed(0)                # the single-process run shuffles from here; the DP engine seeds pass 0 with 0 itself
-    model = DiVAE(corpus, cfg).cuda()
+    model = (StED if kind == "sted" else DiVAE)(corpus, cfg).cuda()
 
     class Keep(logging.Handler):
         lines = []
@@ -338,10 +350,12 @@ def _engine_worker(rank, world, result_dir, data_dir, tag):
     root.addHandler(Keep())
     root.setLevel(logging.INFO)
     c0 = dict(parallel.COLLECTIVES)
-    best = engine.train(model, feeds[0], feeds[1], feeds[2], cfg, evaluators.BleuEvaluator("dp"), gen=utt_utils.generate)
+    best = engine.train(model, feeds[0], feeds[1], feeds[2], cfg, evaluators.BleuEvaluator("dp"), gen=gen)
     torch.cuda.synchronize()
     assert ops.gru_persist_timeouts() == 0
     valid = [l for l in Keep.lines if l.startswith("Valid nll")]
+    if kind == "sted":
+        assert sum("Training phase changed" in l for l in Keep.lines) == 1
     train = [l for l in Keep.lines if "Train " in l and ("/10-(" in l or l.startswith("Pseudo-epoch"))]
     assert len(valid) == 3 and len(train) == 9, (valid, train)
     if world > 1:
@@ -349,7 +363,7 @@ def _engine_worker(rank, world, result_dir, data_dir, tag):
         # "Pseudo-epoch done" line re-reads what the print just before it reduced); the step itself: one forward exchange
         n_valid_batches = feeds[1].data_size // cfg.batch_size
         assert parallel.COLLECTIVES["report"] - c0["report"] == 3 * n_valid_batches + 6, parallel.COLLECTIVES
-        assert parallel.COLLECTIVES["forward"] - c0["forward"] == 30 + 3 * n_valid_batches, parallel.COLLECTIVES
+        assert parallel.COLLECTIVES["forward"] - c0["forward"] == 30 + 3 * n_valid_batches, parallel.COLLECTIVES     # one per forward
     json.dump({"best": best, "valid": valid, "train": train}, open(os.path.join(result_dir, "%s_%d.json" % (tag, rank)), "w"))
     if world > 1:
         dist.barrier()
@@ -360,6 +374,40 @@ def _engine_worker(rank, world, result_dir, data_dir, tag):
 def _numbers(line):
     import re
     return [float(x) for x in re.findall(r"-?\d+\.\d+", line)]
+
+
+def test_engine_train_dialog_model_data_parallel_equals_single_process(tmp_path):
+    """The same for ST-ED (batch of 8 dialog turns over 2 ranks, Stanford fixture): three pseudo-epochs through the phase change
+    -- both ranks freeze the recognition side at the same step, rebuild optimizer and gradient reducer, and go on -- against
+    the one-process run: the same report lines on both ranks (every scalar term classified correctly as a share or as a
+    replicated batch statistic), equal to the one-process lines, and the same checkpoint."""
+    import json
+    sys.path.insert(0, HERE)
+    from helpers import load_golden
+    G = load_golden("corpora")
+    st = tmp_path / "stanford"
+    st.mkdir()
+    inputs = json.loads(str(G["stanford/inputs_json"]))
+    for fname, s in (("kvret_train_public.json", "train"), ("kvret_dev_public.json", "valid"), ("kvret_test_public.json", "test")):
+        (st / fname).write_text(json.dumps(inputs[s]), encoding="utf-8")
+    mp.spawn(_engine_worker, args=(1, str(tmp_path), str(st), "one", "sted"), nprocs=1, join=True)
+    mp.spawn(_engine_worker, args=(2, str(tmp_path), str(st), "two", "sted"), nprocs=2, join=True)
+    one = json.load(open(str(tmp_path / "one_0.json")))
+    r0 = json.load(open(str(tmp_path / "two_0.json")))
+    r1 = json.load(open(str(tmp_path / "two_1.json")))
+    assert r0["valid"] == r1["valid"] and r0["train"] == r1["train"] and r0["best"] == r1["best"]
+    for a, b in zip(one["valid"] + one["train"], r0["valid"] + r0["train"]):
+        na, nb = _numbers(a), _numbers(b)
+        assert len(na) == len(nb) >= 8
+        for x, y in zip(na, nb):
+            assert abs(x - y) <= 3e-3 + 3e-3 * abs(x), (a, b)
+    assert abs(one["best"] - r0["best"]) <= 2e-3 * abs(one["best"])
+    sd1 = torch.load(str(tmp_path / "one" / "model"), weights_only=True, map_location="cpu")
+    sd2 = torch.load(str(tmp_path / "two" / "model"), weights_only=True, map_location="cpu")
+    assert list(sd1) == list(sd2)
+    for k in sd1:
+        d = (sd1[k] - sd2[k]).abs()
+        assert float(d.mean()) < 5e-4 and float(d.max()) < 3e-2, (k, float(d.mean()), float(d.max()))
 
 
 def test_engine_train_data_parallel_equals_single_process(tmp_path):
