@@ -105,7 +105,17 @@ __global__ __launch_bounds__(256) void embed_scatter_small_kernel(const int64_t*
     const int total = s_total;
     for (int e = tid; e < E; e += 256) {
         float acc = sc_val(dout, keep, scale, r, E, e);
-        for (int k = 0; k < total; ++k) acc += sc_val(dout, keep, scale, list[k], E, e);
+        // a frequent id (<s>, the head of a Zipf vocabulary) owns a hundred rows of a 1200-row batch: fetch them eight at a time
+        // -- the additions stay in list order (bit-identical), only the loads stop waiting for each other
+        int k = 0;
+        for (; k + 8 <= total; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = sc_val(dout, keep, scale, list[k + j], E, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; k < total; ++k) acc += sc_val(dout, keep, scale, list[k], E, e);
         dtable[id * E + e] += acc;
     }
 }
