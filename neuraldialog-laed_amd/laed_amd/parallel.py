@@ -120,7 +120,7 @@ def global_terms(loss, replicated=()):
     step itself never needs it.  Identity on one GPU."""
     if not _ENABLED:
         return loss
-    keys = [k for k, v in loss.items() if torch.is_tensor(v) and v.numel() == 1 and k not in replicated]
+    keys = [k for k, v in loss.items() if torch.is_tensor(v) and v.numel() == 1 and v.is_floating_point() and k not in replicated]
     if not keys:
         return loss
     vec = torch.stack([loss[k].detach().reshape(()).float() for k in keys])
